@@ -1,0 +1,48 @@
+"""In-tree build of the HIP library (libpbd_hip.so) for gfx950.
+
+hipcc cross-compiles without a GPU.  Flags that matter for parity:
+  -ffp-contract=off                           no fused multiply-add unless written as one
+  -fhip-fp32-correctly-rounded-divide-sqrt    IEEE fp32 divide / sqrt
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpbd_hip.so")
+SOURCES = ["pbd_capi.hip", "pbd_kernels_features.hip", "pbd_kernels_conv.hip", "pbd_kernels_dp.hip"]
+HEADERS = ["pbd_internal.h", os.path.join("..", "..", "include", "pbd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the HIP library cannot be built")
+    return exe
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

@@ -1,0 +1,1069 @@
+// pbd_capi.hip -- handle, plans, device workspace and the C entry points of include/pbd.h.
+//
+// Host logic restated from the reference for this path:
+//   pyramid geometry            src/HOGFeatures.cpp:95-127, include/HOGFeatures.hpp:74-81
+//   engine wiring               src/PartsBasedDetector.cpp:69-127
+//   Parts index tables          include/Parts.hpp:172-187
+// There is no CPU compute path: every stage runs as a HIP kernel (pbd_kernels_*.hip).
+#include "pbd_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <numeric>
+#include <set>
+
+using namespace pbd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+template <typename T>
+struct DevTable {   // small immutable table uploaded once
+    T *d = nullptr;
+    size_t n = 0;
+    hipError_t upload(const std::vector<T> &h)
+    {
+        release();
+        n = h.size();
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(T));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (d) (void)hipFree(d); d = nullptr; n = 0; }
+};
+
+// ---- pyramid geometry (host) -------------------------------------------------------------------
+// Overload resolution assumed for the reference's expressions: C++11 <cmath>, i.e. pow(float,float)
+// and log(float) are the float versions, pow(float,int) promotes to double.
+int plan_pyramid(int rows, int cols, int sbin, int interval, std::vector<int> &lr, std::vector<int> &lc,
+                 std::vector<float> &scales)
+{
+    const float sfactor = powf(2.0f, 1.0f / (float)interval);             // HOGFeatures.hpp:78
+    const float h = (float)rows, w = (float)cols;
+    const float mn = std::min(h, w);
+    const float ns = 1 + floorf(logf(mn / (5.0f * (float)sbin)) / logf(sfactor));   // HOGFeatures.cpp:99
+    if (!(ns >= 1)) return 0;
+    const int n = (int)ns;
+    if (n > PBD_MAX_LEVELS) return -1;
+    if (n < interval) return -2;   // the reference writes out of bounds here (HOGFeatures.cpp:114-118)
+    lr.assign(n, 0); lc.assign(n, 0); scales.assign(n, 0.f);
+    for (int i = 0; i < interval; ++i) {
+        const float f = (float)((double)1.0f / pow((double)sfactor, (double)i));     // :116
+        lc[i] = (int)lrint((double)(w * f));   // Size_<float> -> Size: cvRound, half to even
+        lr[i] = (int)lrint((double)(h * f));
+        scales[i] = (float)(pow((double)sfactor, (double)i) * (double)sbin);          // :118
+        for (int j = i + interval; j < n; j += interval) {                            // :120-126
+            lc[j] = (lc[j - interval] + 1) / 2;
+            lr[j] = (lr[j - interval] + 1) / 2;
+            scales[j] = 2 * scales[j - interval];
+        }
+    }
+    return n;
+}
+
+inline short sat_short_round(float v)
+{
+    long iv = lrint((double)v);
+    return (short)(iv < -32768 ? -32768 : iv > 32767 ? 32767 : iv);
+}
+
+struct Plan {
+    // key
+    int kind = 0;   // 0: from image size, 1: from explicit feature-map sizes
+    int rows = 0, cols = 0, cn = 0;
+    std::vector<int> key_dims;
+    // geometry
+    int nlevels = 0;
+    std::vector<LevelDesc> lv;
+    std::vector<float> scales;
+    long long pix_per_frame = 0, blk_per_frame = 0, cell_per_frame = 0, npix_resized = 0;
+    int interval = 0;
+    int nrows_flat = 0, ncols_flat = 0;
+    int ntiles = 0;
+    // device tables
+    DevTable<LevelDesc> d_lv;
+    DevTable<ResizeTabX> d_tabx;
+    DevTable<ResizeTabY> d_taby;
+    DevTable<ConvTile> d_tiles;
+    DevTable<int> d_row2level, d_rowoff, d_col2level, d_coloff;
+    DevTable<float> d_scales;
+    void release()
+    {
+        d_lv.release(); d_tabx.release(); d_taby.release(); d_tiles.release();
+        d_row2level.release(); d_rowoff.release(); d_col2level.release(); d_coloff.release(); d_scales.release();
+    }
+    ~Plan() { release(); }
+};
+
+struct Group {   // parts of one tree depth
+    std::vector<DtJob> jobs;
+    std::vector<CombineJob> cjobs;
+    DevTable<DtJob> d_jobs;
+    DevTable<CombineJob> d_cjobs;
+};
+
+struct Prof {
+    bool on = false;
+    struct Rec { int k; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double total[PBD_K_COUNT] = {0};
+    int launches[PBD_K_COUNT] = {0};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void flush()
+    {
+        for (auto &r : recs) {
+            (void)hipEventSynchronize(r.b);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total[r.k] += ms; launches[r.k] += 1; }
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+    void release()
+    {
+        flush();
+        for (auto e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+}  // namespace
+
+struct pbd_handle {
+    pbd_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // model (host copies)
+    int NC = 0, F = 0, flen = 32, sbin = 4, interval = 10, norient = 18, NS = 0, max_parts = 0;
+    float thresh = 0.f;
+    int ksize = 0, Fpad = 0;
+    std::vector<int> filter_ksize, part_offset, parentid, mix_offset, filterid, biasid, defid, ptr_slot, anchors;
+    std::vector<float> biasw, defw;
+    std::vector<Group> groups;       // deepest first
+    std::vector<int> child_slots;
+    std::vector<RootJob> rjobs;
+    std::vector<PartWalk> walk;
+    std::vector<int> walk_off;
+    int JGmax = 0;
+    bool filters_set = false;
+
+    // device model tables
+    DevTable<float> d_wts, d_biasw;
+    DevTable<int> d_child_slots, d_walk_off;
+    DevTable<RootJob> d_rjobs;
+    DevTable<PartWalk> d_walk;
+    DevTable<HogCoord> d_coord;
+    int coord_n = 0;
+
+    // plans
+    std::vector<std::unique_ptr<Plan>> plans;
+    Plan *cur = nullptr;
+    int cur_frames = 0;
+    bool have_features = false, have_resp = false, have_dp = false;
+
+    // workspace
+    DevBuf frames, pyr, hist, norm, feat, resp, msg, Ix, Iy, Ik, rootv, rooti;
+    DevBuf tmp, dt, IxRaw, IyRaw, stk_v, stk_z, stk_s, cand, count, scales_tmp;
+    std::vector<int32_t> cand_host;
+
+    Prof prof;
+};
+
+namespace {
+
+int fail(pbd_handle *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(h, PBD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct ProfScope {
+    pbd_handle *h; int k; hipEvent_t a{}, b{};
+    ProfScope(pbd_handle *h_, int k_) : h(h_), k(k_)
+    {
+        if (h->prof.on) { a = h->prof.get(); b = h->prof.get(); (void)hipEventRecord(a, h->stream); }
+    }
+    ~ProfScope()
+    {
+        if (h->prof.on) { (void)hipEventRecord(b, h->stream); h->prof.recs.push_back({k, a, b}); }
+    }
+};
+
+// ---- plan construction -------------------------------------------------------------------------
+void finish_plan_tables(Plan &P)
+{
+    // flat row / column lookup and conv tiles over the feature maps
+    std::vector<int> row2level, rowoff(P.nlevels + 1, 0), col2level, coloff(P.nlevels + 1, 0);
+    std::vector<ConvTile> tiles;
+    for (int l = 0; l < P.nlevels; ++l) {
+        const LevelDesc &d = P.lv[l];
+        rowoff[l] = (int)row2level.size();
+        coloff[l] = (int)col2level.size();
+        if (d.rows > 0 && d.cols > 0) {
+            for (int y = 0; y < d.rows; ++y) row2level.push_back(l);
+            for (int x = 0; x < d.cols; ++x) col2level.push_back(l);
+            for (int y0 = 0; y0 < d.rows; y0 += kConvTH)
+                for (int x0 = 0; x0 < d.cols; x0 += kConvTW) tiles.push_back({l, y0, x0});
+        }
+    }
+    rowoff[P.nlevels] = (int)row2level.size();
+    coloff[P.nlevels] = (int)col2level.size();
+    P.nrows_flat = (int)row2level.size();
+    P.ncols_flat = (int)col2level.size();
+    P.ntiles = (int)tiles.size();
+    (void)P.d_lv.upload(P.lv);
+    (void)P.d_tiles.upload(tiles);
+    (void)P.d_row2level.upload(row2level);
+    (void)P.d_rowoff.upload(rowoff);
+    (void)P.d_col2level.upload(col2level);
+    (void)P.d_coloff.upload(coloff);
+    (void)P.d_scales.upload(P.scales);
+}
+
+int get_image_plan(pbd_handle *h, int rows, int cols, int cn, Plan **out)
+{
+    for (auto &p : h->plans)
+        if (p->kind == 0 && p->rows == rows && p->cols == cols && p->cn == cn) { *out = p.get(); return PBD_OK; }
+    std::vector<int> lr, lc;
+    std::vector<float> scales;
+    const int n = plan_pyramid(rows, cols, h->sbin, h->interval, lr, lc, scales);
+    if (n <= 0)
+        return fail(h, PBD_ERR_INVALID, "frame %dx%d too small for sbin %d / interval %d (nscales %d)", rows, cols,
+                    h->sbin, h->interval, n);
+    auto P = std::make_unique<Plan>();
+    P->kind = 0; P->rows = rows; P->cols = cols; P->cn = cn;
+    P->nlevels = n; P->scales = scales; P->interval = h->interval;
+    P->lv.resize(n);
+    std::vector<ResizeTabX> tabx;
+    std::vector<ResizeTabY> taby;
+    long long pix = 0, blk = 0, cell = 0;
+    for (int l = 0; l < n; ++l) {
+        LevelDesc &d = P->lv[l];
+        d.img_rows = lr[l]; d.img_cols = lc[l];
+        if (d.img_rows < 4 || d.img_cols < 4) return fail(h, PBD_ERR_INVALID, "pyramid level %d is %dx%d", l, lr[l], lc[l]);
+        d.blk_cols = (int)roundf((float)lc[l] / (float)h->sbin);   // HOGFeatures.cpp:174
+        d.blk_rows = (int)roundf((float)lr[l] / (float)h->sbin);
+        d.cols = std::max(d.blk_cols - 2, 0);
+        d.rows = std::max(d.blk_rows - 2, 0);
+        d.src_level = l >= h->interval ? l - h->interval : -1;
+        d.img_off = pix; d.blk_off = blk; d.cell_off = cell;
+        d.tab_x = d.tab_y = 0;
+        pix += (long long)lr[l] * lc[l];
+        blk += (long long)d.blk_rows * d.blk_cols;
+        cell += (long long)d.rows * d.cols;
+        if (l == h->interval - 1) P->npix_resized = pix;
+        if (l < h->interval) {
+            // cv::resize INTER_LINEAR 8U coefficient tables (OpenCV imgwarp.cpp)
+            const double scale_x = 1. / ((double)lc[l] / cols), scale_y = 1. / ((double)lr[l] / rows);
+            d.tab_x = (int)tabx.size();
+            d.tab_y = (int)taby.size();
+            for (int dx = 0; dx < lc[l]; ++dx) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = (int)floorf(fx);
+                fx -= (float)sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= cols - 1) { fx = 0; sx = cols - 1; }
+                tabx.push_back({sx, sat_short_round((1.f - fx) * 2048), sat_short_round(fx * 2048)});
+            }
+            for (int dy = 0; dy < lr[l]; ++dy) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = (int)floorf(fy);
+                fy -= (float)sy;
+                const int y0 = std::min(std::max(sy, 0), rows - 1), y1 = std::min(std::max(sy + 1, 0), rows - 1);
+                taby.push_back({y0, y1, sat_short_round((1.f - fy) * 2048), sat_short_round(fy * 2048)});
+            }
+        }
+    }
+    P->pix_per_frame = pix; P->blk_per_frame = blk; P->cell_per_frame = cell;
+    if (P->npix_resized == 0) P->npix_resized = pix;
+    HIPCHK(h, P->d_tabx.upload(tabx));
+    HIPCHK(h, P->d_taby.upload(taby));
+    finish_plan_tables(*P);
+    // HOG coordinate table grows with the largest frame seen
+    const int need = std::max(rows, cols) + 4 * h->sbin + 8;
+    if (need > h->coord_n) {
+        std::vector<HogCoord> coord(need);
+        for (int t = 0; t < need; ++t) {   // HOGFeatures.cpp:252-259, T=float
+            const float tp = (float)(((double)(float)t + 0.5) / (double)(float)h->sbin - 0.5);
+            const int ip = (int)floorf(tp);
+            const float v0 = tp - (float)ip;
+            const float v1 = (float)(1.0 - (double)v0);
+            coord[t] = {ip, v0, v1};
+        }
+        HIPCHK(h, h->d_coord.upload(coord));
+        h->coord_n = need;
+    }
+    *out = P.get();
+    h->plans.push_back(std::move(P));
+    if (h->plans.size() > 16) h->plans.erase(h->plans.begin());
+    return PBD_OK;
+}
+
+int get_dims_plan(pbd_handle *h, int nlevels, const int *rows, const int *cols, Plan **out)
+{
+    if (nlevels <= 0 || nlevels > PBD_MAX_LEVELS) return fail(h, PBD_ERR_INVALID, "nlevels %d out of range", nlevels);
+    std::vector<int> key;
+    for (int l = 0; l < nlevels; ++l) {
+        if (rows[l] < 0 || cols[l] < 0 || rows[l] > 32000 || cols[l] > 32000)
+            return fail(h, PBD_ERR_INVALID, "level %d size %dx%d out of range", l, rows[l], cols[l]);
+        key.push_back(rows[l]); key.push_back(cols[l]);
+    }
+    for (auto &p : h->plans)
+        if (p->kind == 1 && p->key_dims == key) { *out = p.get(); return PBD_OK; }
+    auto P = std::make_unique<Plan>();
+    P->kind = 1; P->key_dims = key; P->nlevels = nlevels; P->interval = h->interval;
+    P->lv.resize(nlevels);
+    P->scales.assign(nlevels, 1.f);
+    long long cell = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        LevelDesc &d = P->lv[l];
+        memset(&d, 0, sizeof d);
+        d.rows = rows[l]; d.cols = cols[l]; d.src_level = -1; d.cell_off = cell;
+        cell += (long long)rows[l] * cols[l];
+    }
+    P->cell_per_frame = cell;
+    finish_plan_tables(*P);
+    *out = P.get();
+    h->plans.push_back(std::move(P));
+    if (h->plans.size() > 16) h->plans.erase(h->plans.begin());
+    return PBD_OK;
+}
+
+// ---- model tables --------------------------------------------------------------------------------
+int upload_filters(pbd_handle *h, int nfilters, const float *const *filters, const int *ksize)
+{
+    if (nfilters <= 0) return fail(h, PBD_ERR_INVALID, "no filters");
+    const int K = ksize[0];
+    for (int f = 0; f < nfilters; ++f)
+        if (ksize[f] != K) return fail(h, PBD_ERR_UNSUPPORTED, "filters of different sizes (%d vs %d) are not supported", ksize[f], K);
+    if (K < 1 || K > 7) return fail(h, PBD_ERR_UNSUPPORTED, "filter size %d not supported (1..7)", K);
+    const int Fpad = (nfilters + kConvQ - 1) / kConvQ * kConvQ;
+    // device layout [channel][tap][Fpad]: the 8 weights of a (channel, tap, filter group) are contiguous
+    std::vector<float> w((size_t)32 * K * K * Fpad, 0.f);
+    for (int f = 0; f < nfilters; ++f)
+        for (int t = 0; t < K * K; ++t)
+            for (int c = 0; c < 32; ++c) w[((size_t)c * K * K + t) * Fpad + f] = filters[f][(size_t)t * 32 + c];
+    HIPCHK(h, h->d_wts.upload(w));
+    h->F = nfilters; h->Fpad = Fpad; h->ksize = K;
+    h->filter_ksize.assign(ksize, ksize + nfilters);
+    h->filters_set = true;
+    return PBD_OK;
+}
+
+int build_model(pbd_handle *h, const pbd_model *m)
+{
+    if (m->flen != 32 || m->norient != 18)
+        return fail(h, PBD_ERR_UNSUPPORTED, "flen %d / norient %d: only 32 / 18 are supported", m->flen, m->norient);
+    if (m->ncomponents < 1 || m->nfilters < 1 || m->sbin < 2 || m->interval < 1)
+        return fail(h, PBD_ERR_INVALID, "bad model header");
+    h->NC = m->ncomponents; h->sbin = m->sbin; h->interval = m->interval; h->norient = m->norient;
+    h->thresh = m->thresh;
+    const int totparts = m->part_offset[m->ncomponents];
+    const int totmix = m->mix_offset[totparts];
+    h->part_offset.assign(m->part_offset, m->part_offset + m->ncomponents + 1);
+    h->parentid.assign(m->parentid, m->parentid + totparts);
+    h->mix_offset.assign(m->mix_offset, m->mix_offset + totparts + 1);
+    h->filterid.assign(m->filterid, m->filterid + totmix);
+    h->biasid.assign(m->biasid, m->biasid + totmix);
+    h->defid.assign(m->defid, m->defid + totmix);
+    h->biasw.assign(m->biasw, m->biasw + m->nbias);
+    h->defw.assign(m->defw, m->defw + (size_t)m->ndefs * 4);
+    h->anchors.assign(m->anchors, m->anchors + (size_t)m->ndefs * 2);
+
+    // filters
+    {
+        std::vector<const float *> fp(m->nfilters);
+        for (int f = 0; f < m->nfilters; ++f) fp[f] = m->filters_f32 + m->filter_offset[f];
+        int rc = upload_filters(h, m->nfilters, fp.data(), m->filter_ksize);
+        if (rc != PBD_OK) return rc;
+    }
+
+    // validation + pointer slots + depth
+    h->ptr_slot.assign(totparts, 0);
+    std::vector<int> depth(totparts, 0);
+    int NS = 0, maxdepth = 0;
+    h->max_parts = 0;
+    for (int c = 0; c < h->NC; ++c) {
+        const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
+        if (np < 1) return fail(h, PBD_ERR_INVALID, "component %d has no parts", c);
+        h->max_parts = std::max(h->max_parts, np);
+        std::set<int> seen;
+        for (int p = 0; p < np; ++p) {
+            const int gp = p0 + p, par = h->parentid[gp];
+            const int K = h->mix_offset[gp + 1] - h->mix_offset[gp];
+            if (K < 1 || K > kMaxMix) return fail(h, PBD_ERR_UNSUPPORTED, "part %d has %d mixtures (1..%d supported)", p, K, kMaxMix);
+            if ((p == 0) != (par < 0) || par >= p) return fail(h, PBD_ERR_INVALID, "part %d: parent %d breaks topological order", p, par);
+            for (int mm = 0; mm < K; ++mm) {
+                const int f = h->filterid[h->mix_offset[gp] + mm];
+                if (f < 0 || f >= h->F) return fail(h, PBD_ERR_INVALID, "filter id %d out of range", f);
+                if (!seen.insert(f).second) return fail(h, PBD_ERR_UNSUPPORTED, "filter %d used twice in component %d", f, c);
+            }
+            h->ptr_slot[gp] = NS;
+            if (p > 0) {
+                const int gpar = p0 + par;
+                const int L = h->mix_offset[gpar + 1] - h->mix_offset[gpar];
+                NS += L;
+                depth[gp] = depth[gpar] + 1;
+                maxdepth = std::max(maxdepth, depth[gp]);
+                for (int mm = 0; mm < K; ++mm) {
+                    const int gm = h->mix_offset[gp] + mm;
+                    const int d = h->defid[gm], b = h->biasid[gm];
+                    if (d < 0 || d >= m->ndefs) return fail(h, PBD_ERR_INVALID, "defid %d out of range", d);
+                    if (b < 0 || b + L > m->nbias) return fail(h, PBD_ERR_INVALID, "biasid %d out of range", b);
+                    if (h->defw[(size_t)d * 4 + 0] == 0.f || h->defw[(size_t)d * 4 + 2] == 0.f)
+                        return fail(h, PBD_ERR_INVALID, "deformation %d has a zero quadratic term", d);
+                }
+            } else {
+                const int b = h->biasid[h->mix_offset[gp]];
+                if (b < 0 || b >= m->nbias) return fail(h, PBD_ERR_INVALID, "root biasid %d out of range", b);
+            }
+        }
+    }
+    if (h->max_parts > 80) return fail(h, PBD_ERR_UNSUPPORTED, "%d parts per component (max 80)", h->max_parts);
+    h->NS = NS;
+
+    // children (descending index) per part
+    std::vector<std::vector<int>> children(totparts);
+    for (int c = 0; c < h->NC; ++c) {
+        const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
+        for (int p = np - 1; p > 0; --p) children[p0 + h->parentid[p0 + p]].push_back(p0 + p);
+    }
+
+    // depth groups, deepest first; per job the child slot list already includes the job's mixture
+    h->groups.clear();
+    h->child_slots.clear();
+    h->JGmax = 0;
+    for (int dep = maxdepth; dep >= 1; --dep) {
+        Group g;
+        for (int c = 0; c < h->NC; ++c) {
+            const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
+            for (int p = 1; p < np; ++p) {
+                const int gp = p0 + p;
+                if (depth[gp] != dep) continue;
+                const int gpar = p0 + h->parentid[gp];
+                const int K = h->mix_offset[gp + 1] - h->mix_offset[gp];
+                const int L = h->mix_offset[gpar + 1] - h->mix_offset[gpar];
+                const int job_begin = (int)g.jobs.size();
+                for (int mm = 0; mm < K; ++mm) {
+                    const int gm = h->mix_offset[gp] + mm;
+                    DtJob j{};
+                    j.filter = h->filterid[gm];
+                    j.child_begin = (int)h->child_slots.size();
+                    for (int ch : children[gp]) h->child_slots.push_back(h->ptr_slot[ch] + mm);
+                    j.child_end = (int)h->child_slots.size();
+                    const int d = h->defid[gm];
+                    const float *w = &h->defw[(size_t)d * 4];
+                    j.ax = (double)(-w[0]); j.bx = (double)(-w[1]); j.ay = (double)(-w[2]); j.by = (double)(-w[3]);
+                    j.osx = h->anchors[(size_t)d * 2]; j.osy = h->anchors[(size_t)d * 2 + 1];
+                    g.jobs.push_back(j);
+                }
+                for (int pm = 0; pm < L; ++pm) {
+                    CombineJob cj{};
+                    cj.job_begin = job_begin; cj.nmix = K; cj.slot = h->ptr_slot[gp] + pm;
+                    for (int mm = 0; mm < K; ++mm) cj.bias_off[mm] = h->biasid[h->mix_offset[gp] + mm] + pm;
+                    g.cjobs.push_back(cj);
+                }
+            }
+        }
+        h->JGmax = std::max(h->JGmax, (int)g.jobs.size());
+        h->groups.push_back(std::move(g));
+    }
+    for (auto &g : h->groups) {
+        HIPCHK(h, g.d_jobs.upload(g.jobs));
+        HIPCHK(h, g.d_cjobs.upload(g.cjobs));
+    }
+    // roots: child list holds base slots (mixture added in the kernel)
+    h->rjobs.assign(h->NC, RootJob{});
+    h->walk.clear(); h->walk_off.assign(h->NC + 1, 0);
+    for (int c = 0; c < h->NC; ++c) {
+        const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
+        RootJob &r = h->rjobs[c];
+        r.nmix = h->mix_offset[p0 + 1] - h->mix_offset[p0];
+        for (int mm = 0; mm < r.nmix; ++mm) r.filter[mm] = h->filterid[h->mix_offset[p0] + mm];
+        r.child_begin = (int)h->child_slots.size();
+        for (int ch : children[p0]) h->child_slots.push_back(h->ptr_slot[ch]);
+        r.child_end = (int)h->child_slots.size();
+        r.bias = h->biasw[h->biasid[h->mix_offset[p0]]];
+        h->walk_off[c] = (int)h->walk.size();
+        for (int p = 0; p < np; ++p) {
+            PartWalk w{};
+            w.parent = h->parentid[p0 + p];
+            w.slot = h->ptr_slot[p0 + p];
+            const int K = h->mix_offset[p0 + p + 1] - h->mix_offset[p0 + p];
+            for (int mm = 0; mm < K; ++mm) w.ksize[mm] = m->filter_ksize[h->filterid[h->mix_offset[p0 + p] + mm]];
+            h->walk.push_back(w);
+        }
+    }
+    h->walk_off[h->NC] = (int)h->walk.size();
+    HIPCHK(h, h->d_child_slots.upload(h->child_slots));
+    HIPCHK(h, h->d_rjobs.upload(h->rjobs));
+    HIPCHK(h, h->d_walk.upload(h->walk));
+    HIPCHK(h, h->d_walk_off.upload(h->walk_off));
+    HIPCHK(h, h->d_biasw.upload(h->biasw));
+    return PBD_OK;
+}
+
+// ---- stages --------------------------------------------------------------------------------------
+int run_features(pbd_handle *h, Plan &P, int nframes)
+{
+    const int cn = P.cn;
+    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * cn));
+    HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * sizeof(float)));
+    HIPCHK(h, h->norm.ensure((size_t)nframes * P.blk_per_frame * sizeof(float)));
+    HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * 32 * sizeof(float), 16)));
+    PyrParams pp{};
+    pp.lv = P.d_lv.d; pp.nlevels = P.nlevels; pp.interval = std::min(P.interval, P.nlevels); pp.cn = cn;
+    pp.pix_per_frame = P.pix_per_frame; pp.pyr = h->pyr.as<uint8_t>(); pp.frames = h->frames.as<uint8_t>();
+    pp.rows = P.rows; pp.cols = P.cols; pp.tabx = P.d_tabx.d; pp.taby = P.d_taby.d;
+    {
+        ProfScope ps(h, PBD_K_RESIZE);
+        launch_resize(pp, nframes, P.npix_resized, h->stream);
+    }
+    for (int first = P.interval; first < P.nlevels; first += P.interval) {
+        const int last = std::min(first + P.interval, P.nlevels);
+        const long long base = P.lv[first].img_off;
+        const long long end = (last < P.nlevels) ? P.lv[last].img_off : P.pix_per_frame;
+        ProfScope ps(h, PBD_K_PYRDOWN);
+        launch_pyrdown_range(pp, nframes, first, last, base, end - base, h->stream);
+    }
+    HogParams hp{};
+    hp.lv = P.d_lv.d; hp.nlevels = P.nlevels; hp.cn = cn; hp.sbin = h->sbin;
+    hp.pix_per_frame = P.pix_per_frame; hp.blk_per_frame = P.blk_per_frame; hp.cell_per_frame = P.cell_per_frame;
+    hp.pyr = h->pyr.as<uint8_t>(); hp.coord = h->d_coord.d;
+    hp.hist = h->hist.as<float>(); hp.norm = h->norm.as<float>(); hp.feat = h->feat.as<float>();
+    {
+        ProfScope ps(h, PBD_K_HOG_HIST);
+        launch_hog_hist(hp, nframes, h->stream);
+    }
+    {
+        ProfScope ps(h, PBD_K_HOG_FEAT);
+        launch_hog_feat(hp, nframes, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->have_features = true;
+    return PBD_OK;
+}
+
+int run_conv(pbd_handle *h, Plan &P, int nframes)
+{
+    if (!h->filters_set) return fail(h, PBD_ERR_STATE, "pdf() before setFilters()");
+    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * h->F * sizeof(float), 16)));
+    ConvParams cp{};
+    cp.lv = P.d_lv.d; cp.tiles = P.d_tiles.d; cp.ntiles = P.ntiles;
+    cp.F = h->F; cp.Fpad = h->Fpad; cp.ksize = h->ksize;
+    const int ngroups = h->Fpad / kConvQ;
+    // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
+    const long long wgs = (long long)P.ntiles * nframes;
+    cp.groups_per_block = wgs >= 2048 ? ngroups : std::max(1, (int)(ngroups * wgs / 2048));
+    cp.cell_per_frame = P.cell_per_frame;
+    cp.feat = h->feat.as<float>(); cp.wts = h->d_wts.d; cp.resp = h->resp.as<float>();
+    cp.fma = h->cfg.conv_mode == PBD_CONV_FMA;
+    {
+        ProfScope ps(h, PBD_K_CONV);
+        launch_conv(cp, nframes, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->have_resp = true;
+    return PBD_OK;
+}
+
+int run_dp(pbd_handle *h, Plan &P, int nframes)
+{
+    const size_t cpf = (size_t)P.cell_per_frame;
+    const int NSa = std::max(h->NS, 1);
+    HIPCHK(h, h->msg.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(float), 16)));
+    HIPCHK(h, h->Ix.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(int16_t), 16)));
+    HIPCHK(h, h->Iy.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(int16_t), 16)));
+    HIPCHK(h, h->Ik.ensure(std::max<size_t>((size_t)nframes * cpf * NSa, 16)));
+    HIPCHK(h, h->rootv.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(float), 16)));
+    HIPCHK(h, h->rooti.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(int), 16)));
+    // scratch for one chunk of frames: bounded so that a batch does not multiply the DT intermediates
+    const size_t per_frame = cpf * std::max(h->JGmax, 1);
+    int chunk = nframes;
+    const size_t budget = (size_t)6 << 30;   // bytes of scratch across the seven arrays (22 B / cell-job)
+    while (chunk > 1 && per_frame * chunk * 22 > budget) chunk = (chunk + 1) / 2;
+    HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
+    HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
+    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
+    HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
+    HIPCHK(h, h->stk_v.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
+    HIPCHK(h, h->stk_z.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
+    HIPCHK(h, h->stk_s.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
+
+    DpParams dp{};
+    dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC;
+    dp.cell_per_frame = P.cell_per_frame;
+    dp.resp = h->resp.as<float>(); dp.msg = h->msg.as<float>();
+    dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
+    dp.tmp = h->tmp.as<float>(); dp.dt = h->dt.as<float>();
+    dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
+    dp.stk_v = h->stk_v.as<int16_t>(); dp.stk_z = h->stk_z.as<float>(); dp.stk_s = h->stk_s.as<float>();
+    dp.child_slots = h->d_child_slots.d; dp.biasw = h->d_biasw.d;
+    dp.row2level = P.d_row2level.d; dp.rowoff = P.d_rowoff.d; dp.col2level = P.d_col2level.d; dp.coloff = P.d_coloff.d;
+    dp.nrows_flat = P.nrows_flat; dp.ncols_flat = P.ncols_flat;
+    dp.rootv = h->rootv.as<float>(); dp.rooti = h->rooti.as<int>(); dp.rjobs = h->d_rjobs.d;
+
+    for (int f0 = 0; f0 < nframes; f0 += chunk) {
+        const int nb = std::min(chunk, nframes - f0);
+        dp.frame0 = f0;
+        for (auto &g : h->groups) {
+            dp.JG = (int)g.jobs.size();
+            dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d;
+            { ProfScope ps(h, PBD_K_DT_ROWS); launch_dt_rows(dp, nb, h->stream); }
+            { ProfScope ps(h, PBD_K_DT_COLS); launch_dt_cols(dp, nb, h->stream); }
+            { ProfScope ps(h, PBD_K_DP_COMBINE); launch_dp_combine(dp, (int)g.cjobs.size(), nb, h->stream); }
+        }
+        { ProfScope ps(h, PBD_K_DP_ROOT); launch_dp_root(dp, nb, h->stream); }
+    }
+    HIPCHK(h, hipGetLastError());
+    h->have_dp = true;
+    return PBD_OK;
+}
+
+int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32_t *cand, int capacity, int *ncand)
+{
+    const int stride = 8 + 4 * h->max_parts;
+    const int cap = std::max(h->cfg.max_candidates, 1);
+    HIPCHK(h, h->cand.ensure((size_t)cap * stride * sizeof(int32_t)));
+    HIPCHK(h, h->count.ensure(sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(h->count.p, 0, sizeof(int), h->stream));
+    ArgminParams ap{};
+    ap.lv = P.d_lv.d; ap.nlevels = P.nlevels; ap.NS = h->NS; ap.NC = h->NC; ap.nframes = nframes;
+    ap.cell_per_frame = P.cell_per_frame;
+    ap.rootv = h->rootv.as<float>(); ap.rooti = h->rooti.as<int>();
+    ap.Ix = h->Ix.as<int16_t>(); ap.Iy = h->Iy.as<int16_t>(); ap.Ik = h->Ik.as<uint8_t>();
+    ap.thresh = h->thresh; ap.scales = d_scales;
+    ap.walk = h->d_walk.d; ap.walk_off = h->d_walk_off.d;
+    ap.max_parts = h->max_parts; ap.stride = stride; ap.capacity = cap;
+    ap.count = h->count.as<int>(); ap.cand = h->cand.as<int32_t>();
+    int found = 0;
+    {
+        ProfScope ps(h, PBD_K_ARGMIN);
+        launch_argmin_find(ap, h->stream);
+    }
+    HIPCHK(h, hipMemcpyAsync(&found, h->count.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const bool dev_overflow = found > cap;
+    const int n = std::min(found, cap);
+    if (n > 0) {
+        {
+            ProfScope ps(h, PBD_K_ARGMIN);
+            launch_argmin_walk(ap, n, h->stream);
+        }
+        h->cand_host.resize((size_t)n * stride);
+        HIPCHK(h, hipMemcpyAsync(h->cand_host.data(), h->cand.p, (size_t)n * stride * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                 h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(h, hipGetLastError());
+    // total order (frame, level, component, y, x); the reference's order is nondeterministic
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    const int32_t *ch = h->cand_host.data();
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        const int32_t *A = ch + (size_t)a * stride, *B = ch + (size_t)b * stride;
+        if (A[0] != B[0]) return A[0] < B[0];
+        if (A[2] != B[2]) return A[2] < B[2];
+        if (A[1] != B[1]) return A[1] < B[1];
+        if (A[4] != B[4]) return A[4] < B[4];
+        return A[3] < B[3];
+    });
+    const int nout = std::min(n, capacity);
+    for (int i = 0; i < nout; ++i)
+        memcpy(cand + (size_t)i * stride, ch + (size_t)order[i] * stride, (size_t)stride * sizeof(int32_t));
+    *ncand = nout;
+    if (dev_overflow || n > capacity)
+        return fail(h, PBD_ERR_CAPACITY, "%d candidates found, capacity %d (config max_candidates %d)", found, capacity, cap);
+    return PBD_OK;
+}
+
+int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int cn, int32_t *cand,
+                  int capacity, int *ncand)
+{
+    if (!h || !cand || !ncand) return PBD_ERR_INVALID;
+    if (nframes < 1 || nframes > h->cfg.max_batch)
+        return fail(h, PBD_ERR_INVALID, "nframes %d outside 1..max_batch %d", nframes, h->cfg.max_batch);
+    if (cn != 1 && cn != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", cn);
+    Plan *P = nullptr;
+    int rc = get_image_plan(h, rows, cols, cn, &P);
+    if (rc != PBD_OK) return rc;
+    h->cur = P; h->cur_frames = nframes;
+    h->have_features = h->have_resp = h->have_dp = false;
+    // the kernels read frames through h->frames; alias the caller's device buffer without copying
+    DevBuf saved = h->frames;
+    h->frames.p = const_cast<void *>(d_frames);
+    rc = run_features(h, *P, nframes);
+    h->frames = saved;
+    if (rc != PBD_OK) return rc;
+    if ((rc = run_conv(h, *P, nframes)) != PBD_OK) return rc;
+    if ((rc = run_dp(h, *P, nframes)) != PBD_OK) return rc;
+    return run_argmin(h, *P, nframes, P->d_scales.d, cand, capacity, ncand);
+}
+
+int upload_frames(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int cn, size_t stride_bytes)
+{
+    const size_t row_bytes = (size_t)cols * cn;
+    if (stride_bytes < row_bytes) return fail(h, PBD_ERR_INVALID, "stride %zu < row bytes %zu", stride_bytes, row_bytes);
+    HIPCHK(h, h->frames.ensure((size_t)nframes * rows * row_bytes));
+    for (int i = 0; i < nframes; ++i)
+        HIPCHK(h, hipMemcpy2DAsync(h->frames.as<uint8_t>() + (size_t)i * rows * row_bytes, row_bytes, imgs[i], stride_bytes,
+                                   row_bytes, rows, hipMemcpyHostToDevice, h->stream));
+    return PBD_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char *pbd_version(void) { return "pbd-hip 0.1 (gfx950)"; }
+
+const char *pbd_last_error(const pbd_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pbd_create(const pbd_model *model, const pbd_config *config, pbd_handle **out)
+{
+    if (!model || !config || !out) return fail(nullptr, PBD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (config->real_type != PBD_REAL_F32)
+        return fail(nullptr, PBD_ERR_UNSUPPORTED, "real_type %d: only PBD_REAL_F32 is built", config->real_type);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, PBD_ERR_HIP, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (config->device < 0 || config->device >= ndev) return fail(nullptr, PBD_ERR_INVALID, "device %d of %d", config->device, ndev);
+    e = hipSetDevice(config->device);
+    if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    auto h = std::make_unique<pbd_handle>();
+    h->cfg = *config;
+    if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
+    if (h->cfg.max_candidates < 1) h->cfg.max_candidates = 65536;
+    if (config->stream) {
+        h->stream = reinterpret_cast<hipStream_t>(config->stream);
+    } else {
+        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        h->own_stream = true;
+    }
+    int rc = build_model(h.get(), model);
+    if (rc != PBD_OK) {
+        g_create_error = h->err;
+        pbd_destroy(h.release());
+        return rc;
+    }
+    *out = h.release();
+    return PBD_OK;
+}
+
+void pbd_destroy(pbd_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->prof.release();
+    for (DevBuf *b : {&h->frames, &h->pyr, &h->hist, &h->norm, &h->feat, &h->resp, &h->msg, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
+                      &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk_v, &h->stk_z, &h->stk_s, &h->cand, &h->count,
+                      &h->scales_tmp})
+        b->release();
+    h->d_wts.release(); h->d_biasw.release(); h->d_child_slots.release(); h->d_walk_off.release();
+    h->d_rjobs.release(); h->d_walk.release(); h->d_coord.release();
+    for (auto &g : h->groups) { g.d_jobs.release(); g.d_cjobs.release(); }
+    h->plans.clear();
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int pbd_candidate_stride(const pbd_handle *h) { return h ? 8 + 4 * h->max_parts : 0; }
+int pbd_binsize(const pbd_handle *h) { return h ? h->sbin : 0; }
+int pbd_num_ptr_slots(const pbd_handle *h) { return h ? h->NS : 0; }
+int pbd_ptr_slot(const pbd_handle *h, int component, int part)
+{
+    if (!h || component < 0 || component >= h->NC) return -1;
+    const int p0 = h->part_offset[component];
+    if (part < 0 || p0 + part >= h->part_offset[component + 1]) return -1;
+    return h->ptr_slot[p0 + part];
+}
+
+int pbd_pyramid_plan(pbd_handle *h, int rows, int cols, int *nlevels, int *img_rows, int *img_cols, int *feat_rows,
+                     int *feat_cols, float *scales)
+{
+    if (!h || !nlevels) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    Plan *P = nullptr;
+    int rc = get_image_plan(h, rows, cols, 3, &P);
+    if (rc != PBD_OK) return rc;
+    *nlevels = P->nlevels;
+    for (int l = 0; l < P->nlevels; ++l) {
+        if (img_rows) img_rows[l] = P->lv[l].img_rows;
+        if (img_cols) img_cols[l] = P->lv[l].img_cols;
+        if (feat_rows) feat_rows[l] = P->lv[l].rows;
+        if (feat_cols) feat_cols[l] = P->lv[l].cols;
+        if (scales) scales[l] = P->scales[l];
+    }
+    return PBD_OK;
+}
+
+int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int channels, size_t stride_bytes,
+                         int depth_code, float *const *feat)
+{
+    if (!h || !img || !feat) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    if (depth_code != 0) return fail(h, PBD_ERR_UNSUPPORTED, "image depth code %d: only 8-bit unsigned is supported", depth_code);
+    if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
+    Plan *P = nullptr;
+    int rc = get_image_plan(h, rows, cols, channels, &P);
+    if (rc != PBD_OK) return rc;
+    if ((rc = upload_frames(h, 1, &img, rows, cols, channels, stride_bytes)) != PBD_OK) return rc;
+    h->cur = P; h->cur_frames = 1;
+    h->have_features = h->have_resp = h->have_dp = false;
+    if ((rc = run_features(h, *P, 1)) != PBD_OK) return rc;
+    for (int l = 0; l < P->nlevels; ++l) {
+        const LevelDesc &d = P->lv[l];
+        const size_t n = (size_t)d.rows * d.cols * 32;
+        if (n && feat[l])
+            HIPCHK(h, hipMemcpyAsync(feat[l], h->feat.as<float>() + (size_t)d.cell_off * 32, n * sizeof(float),
+                                     hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PBD_OK;
+}
+
+int pbd_get_pyramid_image(pbd_handle *h, int frame, int level, uint8_t *dst)
+{
+    if (!h || !dst) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    if (!h->cur || h->cur->kind != 0 || !h->have_features) return fail(h, PBD_ERR_STATE, "no pyramid has been computed");
+    Plan &P = *h->cur;
+    if (frame < 0 || frame >= h->cur_frames || level < 0 || level >= P.nlevels) return fail(h, PBD_ERR_INVALID, "frame/level out of range");
+    const LevelDesc &d = P.lv[level];
+    HIPCHK(h, hipMemcpyAsync(dst, h->pyr.as<uint8_t>() + ((size_t)frame * P.pix_per_frame + d.img_off) * P.cn,
+                             (size_t)d.img_rows * d.img_cols * P.cn, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PBD_OK;
+}
+
+int pbd_conv_set_filters(pbd_handle *h, int nfilters, const float *const *filters, const int *ksize)
+{
+    if (!h || !filters || !ksize) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return upload_filters(h, nfilters, filters, ksize);
+}
+
+int pbd_conv_pdf(pbd_handle *h, int nlevels, const float *const *feat, const int *rows, const int *cols, float *const *resp)
+{
+    if (!h || !feat || !rows || !cols || !resp) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    Plan *P = nullptr;
+    int rc = get_dims_plan(h, nlevels, rows, cols, &P);
+    if (rc != PBD_OK) return rc;
+    HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)P->cell_per_frame * 32 * sizeof(float), 16)));
+    for (int l = 0; l < nlevels; ++l) {
+        const size_t n = (size_t)rows[l] * cols[l] * 32;
+        if (n) HIPCHK(h, hipMemcpyAsync(h->feat.as<float>() + (size_t)P->lv[l].cell_off * 32, feat[l], n * sizeof(float),
+                                        hipMemcpyHostToDevice, h->stream));
+    }
+    h->cur = P; h->cur_frames = 1; h->have_features = true; h->have_resp = h->have_dp = false;
+    if ((rc = run_conv(h, *P, 1)) != PBD_OK) return rc;
+    for (int l = 0; l < nlevels; ++l) {
+        const size_t n = (size_t)rows[l] * cols[l] * h->F;
+        if (n) HIPCHK(h, hipMemcpyAsync(resp[l], h->resp.as<float>() + (size_t)P->lv[l].cell_off * h->F, n * sizeof(float),
+                                        hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PBD_OK;
+}
+
+int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, const float *const *resp, int32_t *const *Ix,
+               int32_t *const *Iy, int32_t *const *Ik, float *const *rootv, int32_t *const *rooti)
+{
+    if (!h || !rows || !cols || !resp) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    Plan *P = nullptr;
+    int rc = get_dims_plan(h, nlevels, rows, cols, &P);
+    if (rc != PBD_OK) return rc;
+    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)P->cell_per_frame * h->F * sizeof(float), 16)));
+    for (int l = 0; l < nlevels; ++l) {
+        const size_t n = (size_t)rows[l] * cols[l] * h->F;
+        if (n) HIPCHK(h, hipMemcpyAsync(h->resp.as<float>() + (size_t)P->lv[l].cell_off * h->F, resp[l], n * sizeof(float),
+                                        hipMemcpyHostToDevice, h->stream));
+    }
+    h->cur = P; h->cur_frames = 1; h->have_resp = true; h->have_dp = false;
+    if ((rc = run_dp(h, *P, 1)) != PBD_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<int16_t> t16;
+    std::vector<uint8_t> t8;
+    for (int l = 0; l < nlevels; ++l) {
+        const size_t hw = (size_t)rows[l] * cols[l];
+        if (!hw) continue;
+        const size_t n = hw * h->NS, off = (size_t)P->lv[l].cell_off * h->NS;
+        if (n) {
+            t16.resize(n); t8.resize(n);
+            if (Ix && Ix[l]) {
+                HIPCHK(h, hipMemcpy(t16.data(), h->Ix.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < n; ++i) Ix[l][i] = t16[i];
+            }
+            if (Iy && Iy[l]) {
+                HIPCHK(h, hipMemcpy(t16.data(), h->Iy.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < n; ++i) Iy[l][i] = t16[i];
+            }
+            if (Ik && Ik[l]) {
+                HIPCHK(h, hipMemcpy(t8.data(), h->Ik.as<uint8_t>() + off, n, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < n; ++i) Ik[l][i] = t8[i];
+            }
+        }
+        const size_t roff = (size_t)P->lv[l].cell_off * h->NC;
+        if (rootv && rootv[l]) HIPCHK(h, hipMemcpy(rootv[l], h->rootv.as<float>() + roff, hw * h->NC * sizeof(float), hipMemcpyDeviceToHost));
+        if (rooti && rooti[l]) HIPCHK(h, hipMemcpy(rooti[l], h->rooti.as<int>() + roff, hw * h->NC * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return PBD_OK;
+}
+
+int pbd_dp_argmin(pbd_handle *h, const float *scales, int32_t *cand, int capacity, int *ncand)
+{
+    if (!h || !scales || !cand || !ncand) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    if (!h->cur || !h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
+    Plan &P = *h->cur;
+    HIPCHK(h, h->scales_tmp.ensure(sizeof(float) * PBD_MAX_LEVELS));
+    HIPCHK(h, hipMemcpyAsync(h->scales_tmp.p, scales, sizeof(float) * P.nlevels, hipMemcpyHostToDevice, h->stream));
+    return run_argmin(h, P, h->cur_frames, h->scales_tmp.as<float>(), cand, capacity, ncand);
+}
+
+int pbd_detect(pbd_handle *h, const void *img, int rows, int cols, int channels, size_t stride_bytes, int32_t *cand,
+               int capacity, int *ncand)
+{
+    return pbd_detect_batch(h, 1, &img, rows, cols, channels, stride_bytes, cand, capacity, ncand);
+}
+
+int pbd_detect_batch(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int channels,
+                     size_t stride_bytes, int32_t *cand, int capacity, int *ncand)
+{
+    if (!h || !imgs || !cand || !ncand) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    if (nframes < 1 || nframes > h->cfg.max_batch)
+        return fail(h, PBD_ERR_INVALID, "nframes %d outside 1..max_batch %d", nframes, h->cfg.max_batch);
+    if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
+    int rc = upload_frames(h, nframes, imgs, rows, cols, channels, stride_bytes);
+    if (rc != PBD_OK) return rc;
+    return detect_device(h, nframes, h->frames.p, rows, cols, channels, cand, capacity, ncand);
+}
+
+int pbd_detect_batch_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels,
+                            int32_t *cand, int capacity, int *ncand)
+{
+    if (!h || !d_frames) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    return detect_device(h, nframes, d_frames, rows, cols, channels, cand, capacity, ncand);
+}
+
+int pbd_get_stage(pbd_handle *h, int stage, int frame, int level, void *dst, size_t dst_bytes)
+{
+    if (!h || !dst) return PBD_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    if (!h->cur) return fail(h, PBD_ERR_STATE, "nothing has been computed");
+    Plan &P = *h->cur;
+    if (frame < 0 || frame >= h->cur_frames || level < 0 || level >= P.nlevels) return fail(h, PBD_ERR_INVALID, "frame/level out of range");
+    const LevelDesc &d = P.lv[level];
+    const size_t hw = (size_t)d.rows * d.cols, cpf = (size_t)P.cell_per_frame;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (stage) {
+    case PBD_STAGE_FEATURES:
+        if (!h->have_features) return fail(h, PBD_ERR_STATE, "features not computed");
+        src = h->feat.as<float>() + ((size_t)frame * cpf + d.cell_off) * 32; bytes = hw * 32 * sizeof(float); break;
+    case PBD_STAGE_RESPONSES:
+        if (!h->have_resp) return fail(h, PBD_ERR_STATE, "responses not computed");
+        src = h->resp.as<float>() + ((size_t)frame * cpf + d.cell_off) * h->F; bytes = hw * h->F * sizeof(float); break;
+    case PBD_STAGE_ROOTV:
+        if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
+        src = h->rootv.as<float>() + ((size_t)frame * cpf + d.cell_off) * h->NC; bytes = hw * h->NC * sizeof(float); break;
+    case PBD_STAGE_ROOTI:
+        if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
+        src = h->rooti.as<int>() + ((size_t)frame * cpf + d.cell_off) * h->NC; bytes = hw * h->NC * sizeof(int); break;
+    default: return fail(h, PBD_ERR_INVALID, "unknown stage %d", stage);
+    }
+    if (dst_bytes < bytes) return fail(h, PBD_ERR_INVALID, "destination holds %zu bytes, need %zu", dst_bytes, bytes);
+    if (bytes) HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PBD_OK;
+}
+
+int pbd_profile_enable(pbd_handle *h, int on)
+{
+    if (!h) return PBD_ERR_INVALID;
+    h->prof.flush();
+    h->prof.on = on != 0;
+    return PBD_OK;
+}
+int pbd_profile_reset(pbd_handle *h)
+{
+    if (!h) return PBD_ERR_INVALID;
+    h->prof.flush();
+    for (int k = 0; k < PBD_K_COUNT; ++k) { h->prof.total[k] = 0; h->prof.launches[k] = 0; }
+    return PBD_OK;
+}
+int pbd_profile_read(pbd_handle *h, int k, double *total_ms, int *launches)
+{
+    if (!h || k < 0 || k >= PBD_K_COUNT) return PBD_ERR_INVALID;
+    h->prof.flush();
+    if (total_ms) *total_ms = h->prof.total[k];
+    if (launches) *launches = h->prof.launches[k];
+    return PBD_OK;
+}
+const char *pbd_kernel_name(int k)
+{
+    static const char *names[PBD_K_COUNT] = {"k_resize", "k_pyrdown", "k_hog_hist", "k_hog_feat", "k_conv", "k_dt_rows",
+                                             "k_dt_cols", "k_dp_combine", "k_dp_root", "k_argmin"};
+    return (k >= 0 && k < PBD_K_COUNT) ? names[k] : "?";
+}
+int pbd_synchronize(pbd_handle *h)
+{
+    if (!h) return PBD_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PBD_OK;
+}
+
+}  // extern "C"

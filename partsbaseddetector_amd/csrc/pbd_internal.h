@@ -1,0 +1,160 @@
+// pbd_internal.h -- shared declarations of the HIP implementation behind include/pbd.h.
+// gfx950 (MI355X) only.  Not part of the public interface.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pbd.h"
+
+namespace pbd {
+
+// One pyramid level as the kernels see it.  Offsets are per frame; a frame's slice of a buffer
+// starts at frame * (per-frame total).
+struct LevelDesc {
+    int img_rows, img_cols;   // level image (pixels)
+    int blk_rows, blk_cols;   // HOG blocks = round(dim / sbin)             (src/HOGFeatures.cpp:174)
+    int rows, cols;           // feature / response map = blocks - 2         (:175)
+    int src_level;            // pyrDown source level (level - interval), -1 for resized levels
+    int tab_x, tab_y;         // offsets into the resize tables (levels < interval)
+    long long img_off;        // pixel offset of the level image (multiply by channels for bytes)
+    long long blk_off;        // block offset
+    long long cell_off;       // cell offset
+};
+
+// resize tables (cv::resize INTER_LINEAR 8U fixed point)
+struct ResizeTabX { int sx; short a0, a1; };
+struct ResizeTabY { int y0, y1; short b0, b1; };
+
+// bilinear cell weights of a pixel coordinate (src/HOGFeatures.cpp:252-259), depends on sbin only
+struct HogCoord { int ip; float v0, v1; };
+
+struct ConvTile { int level; int y0, x0; };
+
+// distance-transform job = (part, child mixture) of one tree-depth group
+struct DtJob {
+    int filter;               // response plane of this (part, mixture)
+    int child_begin, child_end; // range in the child-slot list (already in descending child order)
+    int osx, osy;             // anchor
+    double ax, bx, ay, by;    // Quadratic(-w0,-w1), Quadratic(-w2,-w3)  (src/DynamicProgram.cpp:125-127)
+};
+
+// combine job = (part, parent mixture) of one tree-depth group
+struct CombineJob {
+    int job_begin;            // first DtJob (index within the group) of this part
+    int nmix;                 // child mixtures K
+    int slot;                 // back-pointer / message slot = ptr_slot[part] + parent mixture
+    int bias_off[8];          // biasid[part][mm] + parent mixture, mm < K   (K <= 8)
+};
+
+struct RootJob {              // one per component
+    int nmix;
+    int filter[8];
+    int child_begin, child_end;
+    float bias;
+};
+
+struct PartWalk {             // argmin tree walk, one per part of a component
+    int parent;               // local parent index
+    int slot;                 // ptr_slot
+    int ksize[8];             // filter size per mixture (xsize == ysize == rows, include/Parts.hpp:185-187)
+};
+
+constexpr int kMaxMix = 8;
+constexpr int kConvTW = 32, kConvTH = 8, kConvQ = 8;
+
+// ---- launch parameter blocks ---------------------------------------------------------------
+struct PyrParams {
+    const LevelDesc *lv;
+    int nlevels, interval, cn;
+    long long pix_per_frame;      // pixels (not bytes) of all level images of one frame
+    uint8_t *pyr;                 // [frames][pix_per_frame*cn]
+    const uint8_t *frames;        // [frames][rows*cols*cn] dense
+    int rows, cols;
+    const ResizeTabX *tabx;
+    const ResizeTabY *taby;
+};
+
+struct HogParams {
+    const LevelDesc *lv;
+    int nlevels, cn, sbin;
+    long long pix_per_frame, blk_per_frame, cell_per_frame;
+    const uint8_t *pyr;
+    const HogCoord *coord;
+    float *hist;                  // [frames][18][blk_per_frame]
+    float *norm;                  // [frames][blk_per_frame]
+    float *feat;                  // [frames][cell_per_frame*32]
+};
+
+struct ConvParams {
+    const LevelDesc *lv;
+    const ConvTile *tiles;
+    int ntiles;
+    int F, Fpad, ksize;
+    int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
+    long long cell_per_frame;
+    const float *feat;            // [frames][cell_per_frame*32]
+    const float *wts;             // [32][k*k][Fpad]
+    float *resp;                  // [frames][cell_per_frame*F], level-major then filter planes
+    int fma;
+};
+
+struct DpParams {
+    const LevelDesc *lv;
+    int nlevels;
+    int F, NS, NC;                // filters, pointer slots, components
+    long long cell_per_frame;
+    int frame0;                   // first frame of this chunk (absolute index into resp/msg/ptr buffers)
+    const float *resp;
+    float *msg;                   // [frames][cell_per_frame*NS]
+    int16_t *Ix, *Iy;             // [frames][cell_per_frame*NS]
+    uint8_t *Ik;
+    // group scratch, indexed by chunk-local frame
+    int JG;                       // jobs in this group
+    float *tmp, *dt;              // [chunk][cell_per_frame*JG]
+    int16_t *IxRaw, *IyRaw;
+    int16_t *stk_v; float *stk_z, *stk_s;
+    const DtJob *jobs;
+    const int *child_slots;
+    const CombineJob *cjobs;
+    const float *biasw;
+    const int *row2level; const int *rowoff;   // flat row -> level, level -> first flat row
+    const int *col2level; const int *coloff;
+    int nrows_flat, ncols_flat;
+    float *rootv; int *rooti;     // [frames][cell_per_frame*NC]
+    const RootJob *rjobs;
+};
+
+struct ArgminParams {
+    const LevelDesc *lv;
+    int nlevels, NS, NC, nframes;
+    long long cell_per_frame;
+    const float *rootv; const int *rooti;
+    const int16_t *Ix, *Iy; const uint8_t *Ik;
+    float thresh;
+    const float *scales;          // [nlevels]
+    const PartWalk *walk;         // all components concatenated
+    const int *walk_off;          // [NC+1]
+    int max_parts, stride, capacity;
+    int *count;                   // device counter
+    int32_t *cand;                // [capacity][stride]
+};
+
+// ---- launchers (pbd_kernels_*.hip) ---------------------------------------------------------
+void launch_resize(const PyrParams &p, int nframes, long long npix_resized, hipStream_t s);
+void launch_pyrdown_range(const PyrParams &p, int nframes, int first_level, int last_level, long long base,
+                          long long npix, hipStream_t s);
+void launch_hog_hist(const HogParams &p, int nframes, hipStream_t s);
+void launch_hog_feat(const HogParams &p, int nframes, hipStream_t s);
+void launch_conv(const ConvParams &p, int nframes, hipStream_t s);
+void launch_dt_rows(const DpParams &p, int nframes, hipStream_t s);
+void launch_dt_cols(const DpParams &p, int nframes, hipStream_t s);
+void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, hipStream_t s);
+void launch_dp_root(const DpParams &p, int nframes, hipStream_t s);
+void launch_argmin_find(const ArgminParams &p, hipStream_t s);
+void launch_argmin_walk(const ArgminParams &p, int ncand, hipStream_t s);
+
+}  // namespace pbd

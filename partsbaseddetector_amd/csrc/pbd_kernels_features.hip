@@ -1,0 +1,280 @@
+// pbd_kernels_features.hip -- pyramid resampling and HOG feature kernels (gfx950).
+//
+// Replaces HOGFeatures<T>::pyramid / features<uint8_t> (reference src/HOGFeatures.cpp:95-341) for
+// T=float.  All arithmetic is ordered exactly as the reference's; the file is compiled with
+// -ffp-contract=off so no multiply-add is fused.
+#include "pbd_internal.h"
+
+namespace pbd {
+
+// level containing flat element `idx` for the offsets selected by OFF (0 img, 1 blk, 2 cell)
+template <int OFF>
+__device__ __forceinline__ long long lv_off(const LevelDesc &d)
+{
+    return OFF == 0 ? d.img_off : (OFF == 1 ? d.blk_off : d.cell_off);
+}
+template <int OFF>
+__device__ __forceinline__ int find_level(const LevelDesc *lv, int lo, int hi, long long idx)
+{   // largest l in [lo, hi) with off(l) <= idx  (offsets are non-decreasing)
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (lv_off<OFF>(lv[mid]) <= idx) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::resize, INTER_LINEAR, 8-bit (call site src/HOGFeatures.cpp:116).  Coefficient tables are
+// built on the host (pbd_plan.cpp); here: horizontal pass in int, vertical pass
+// ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2 >> 2.  One thread per destination pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(PyrParams p, long long npix)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const int frame = blockIdx.y;
+    const int l = find_level<0>(p.lv, 0, p.interval, idx);
+    const LevelDesc d = p.lv[l];
+    const int local = (int)(idx - d.img_off);
+    const int dy = local / d.img_cols, dx = local - dy * d.img_cols;
+    const ResizeTabX tx = p.tabx[d.tab_x + dx];
+    const ResizeTabY ty = p.taby[d.tab_y + dy];
+    const int cn = p.cn;
+    const uint8_t *src = p.frames + (size_t)frame * p.rows * p.cols * cn;
+    const uint8_t *S0 = src + (size_t)ty.y0 * p.cols * cn, *S1 = src + (size_t)ty.y1 * p.cols * cn;
+    const int sx = tx.sx, sx1 = sx + 1 < p.cols ? sx + 1 : sx;
+    uint8_t *D = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off + local) * cn;
+    for (int c = 0; c < cn; ++c) {
+        const int r0 = S0[sx * cn + c] * tx.a0 + S0[sx1 * cn + c] * tx.a1;
+        const int r1 = S1[sx * cn + c] * tx.a0 + S1[sx1 * cn + c] * tx.a1;
+        D[c] = (uint8_t)((((ty.b0 * (r0 >> 4)) >> 16) + ((ty.b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+void launch_resize(const PyrParams &p, int nframes, long long npix, hipStream_t s)
+{
+    dim3 grid((unsigned)((npix + 255) / 256), nframes);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, p, npix);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::pyrDown, 8-bit (call site src/HOGFeatures.cpp:122): [1 4 6 4 1] x [1 4 6 4 1],
+// BORDER_REFLECT_101, (sum + 128) >> 8.  One thread per destination pixel of the levels
+// [first_level, last_level), whose sources are the levels `interval` below.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_pyrdown(PyrParams p, int first_level, int last_level, long long base, long long npix)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const int frame = blockIdx.y;
+    const int l = find_level<0>(p.lv, first_level, last_level, idx + base);
+    const LevelDesc d = p.lv[l];
+    const LevelDesc sd = p.lv[d.src_level];
+    const int local = (int)(idx + base - d.img_off);
+    const int y = local / d.img_cols, x = local - y * d.img_cols;
+    const int cn = p.cn;
+    const uint8_t *S = p.pyr + ((size_t)frame * p.pix_per_frame + sd.img_off) * cn;
+    uint8_t *D = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off + local) * cn;
+    int xs[5], ys[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        xs[k] = reflect101(2 * x - 2 + k, sd.img_cols) * cn;
+        ys[k] = reflect101(2 * y - 2 + k, sd.img_rows);
+    }
+    for (int c = 0; c < cn; ++c) {
+        int r[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint8_t *R = S + (size_t)ys[k] * sd.img_cols * cn + c;
+            r[k] = R[xs[2]] * 6 + (R[xs[1]] + R[xs[3]]) * 4 + R[xs[0]] + R[xs[4]];
+        }
+        D[c] = (uint8_t)((r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4] + 128) >> 8);
+    }
+}
+
+void launch_pyrdown_range(const PyrParams &p, int nframes, int first_level, int last_level, long long base,
+                          long long npix, hipStream_t s)
+{
+    dim3 grid((unsigned)((npix + 255) / 256), nframes);
+    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+}
+
+// ------------------------------------------------------------------------------------------------
+// HOG cell histograms, gather form.  One thread per block (cell of the `blocks` grid): it walks the
+// source pixels that the reference's scatter loop (src/HOGFeatures.cpp:202-267) adds into this
+// block, in the same raster order, so every bin sees the same sequence of float additions.
+// Bins are 18 registers; the selected bin is updated through predicated adds of +0.0f, which leave
+// a non-negative sum unchanged.  Also writes the block energy (:270-283).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.blk_per_frame) return;
+    const int frame = blockIdx.y;
+    const int l = find_level<1>(p.lv, 0, p.nlevels, idx);
+    const LevelDesc d = p.lv[l];
+    const int local = (int)(idx - d.blk_off);
+    const int by = local / d.blk_cols, bx = local - by * d.blk_cols;
+    const int cn = p.cn, sbin = p.sbin;
+    const int rows = d.img_rows, cols = d.img_cols;
+    const int vish = d.blk_rows * sbin, visw = d.blk_cols * sbin;
+    const uint8_t *im = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off) * cn;
+    const size_t stride = (size_t)cols * cn;
+
+    const float uu[9] = {1.000f, 0.9397f, 0.7660f, 0.5000f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
+    const float vv[9] = {0.000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
+
+    float h[18];
+#pragma unroll
+    for (int o = 0; o < 18; ++o) h[o] = 0.0f;
+
+    int ylo = sbin * by - sbin, yhi = sbin * by + 2 * sbin;
+    int xlo = sbin * bx - sbin, xhi = sbin * bx + 2 * sbin;
+    if (ylo < 1) ylo = 1;
+    if (xlo < 1) xlo = 1;
+    if (yhi > vish - 1) yhi = vish - 1;
+    if (xhi > visw - 1) xhi = visw - 1;
+
+    for (int y = ylo; y < yhi; ++y) {
+        const HogCoord cy = p.coord[y];
+        float wy;
+        if (cy.ip == by) wy = cy.v1;            // this block is (iyp, .): weight vy1
+        else if (cy.ip + 1 == by) wy = cy.v0;   // this block is (iyp+1, .): weight vy0
+        else continue;
+        const int ys = y < rows - 2 ? y : rows - 2;
+        for (int x = xlo; x < xhi; ++x) {
+            const HogCoord cx = p.coord[x];
+            float wx;
+            if (cx.ip == bx) wx = cx.v1;
+            else if (cx.ip + 1 == bx) wx = cx.v0;
+            else continue;
+            const int xs = x < cols - 2 ? x : cols - 2;
+            float dx, dy, v;
+            if (cn == 1) {
+                const uint8_t *s = im + xs + (size_t)ys * stride;
+                dy = (float)((int)s[stride] - (int)*(s - stride));
+                dx = (float)((int)s[1] - (int)s[-1]);
+                v = dx * dx + dy * dy;
+            } else {
+                const uint8_t *s = im + 3 * xs + (size_t)ys * stride;
+                const float dyb = (float)((int)s[stride] - (int)*(s - stride));
+                const float dxb = (float)((int)s[3] - (int)s[-3]);
+                const float vb = dxb * dxb + dyb * dyb;
+                const float dyg = (float)((int)s[stride + 1] - (int)*(s - stride + 1));
+                const float dxg = (float)((int)s[4] - (int)s[-2]);
+                const float vg = dxg * dxg + dyg * dyg;
+                dy = (float)((int)s[stride + 2] - (int)*(s - stride + 2));
+                dx = (float)((int)s[5] - (int)s[-1]);
+                v = dx * dx + dy * dy;
+                if (vg > v) { v = vg; dx = dxg; dy = dyg; }
+                if (vb > v) { v = vb; dx = dxb; dy = dyb; }
+            }
+            float best_dot = 0.0f;
+            int best_o = 0;
+#pragma unroll
+            for (int o = 0; o < 9; ++o) {
+                const float dot = uu[o] * dx + vv[o] * dy;
+                if (dot > best_dot) { best_dot = dot; best_o = o; }
+                else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
+            }
+            v = sqrtf(v);
+            // the four scatter lines multiply (vy?*vx?) first, then by v; float products commute
+            const float contrib = (wy * wx) * v;
+#pragma unroll
+            for (int o = 0; o < 18; ++o) h[o] += (o == best_o) ? contrib : 0.0f;
+        }
+    }
+    float *hist = p.hist + (size_t)frame * 18 * p.blk_per_frame + idx;
+#pragma unroll
+    for (int o = 0; o < 18; ++o) hist[(size_t)o * p.blk_per_frame] = h[o];
+    float e = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+        const float t = h[o] + h[o + 9];
+        e += t * t;
+    }
+    p.norm[(size_t)frame * p.blk_per_frame + idx] = e;
+}
+
+void launch_hog_hist(const HogParams &p, int nframes, hipStream_t s)
+{
+    dim3 grid((unsigned)((p.blk_per_frame + 255) / 256), nframes);
+    hipLaunchKernelGGL(k_hog_hist, grid, dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Normalisation and the 32 output channels per interior cell (src/HOGFeatures.cpp:286-340).
+// One thread per cell.  The four normalisers are evaluated in double as the reference does.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hog_norm(const float *n, int stride)
+{
+    const float s4 = ((n[0] + n[1]) + n[stride]) + n[stride + 1];
+    return (float)(1.0 / sqrt((double)s4 + 0.0001));
+}
+
+__global__ __launch_bounds__(256) void k_hog_feat(HogParams p)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.cell_per_frame) return;
+    const int frame = blockIdx.y;
+    const int l = find_level<2>(p.lv, 0, p.nlevels, idx);
+    const LevelDesc d = p.lv[l];
+    const int local = (int)(idx - d.cell_off);
+    const int y = local / d.cols, x = local - y * d.cols;
+    const int bw = d.blk_cols;
+    const float *norm = p.norm + (size_t)frame * p.blk_per_frame + d.blk_off;
+    const float n1 = hog_norm(norm + (size_t)(y + 1) * bw + (x + 1), bw);
+    const float n2 = hog_norm(norm + (size_t)y * bw + (x + 1), bw);
+    const float n3 = hog_norm(norm + (size_t)(y + 1) * bw + x, bw);
+    const float n4 = hog_norm(norm + (size_t)y * bw + x, bw);
+    const float *hist = p.hist + (size_t)frame * 18 * p.blk_per_frame + d.blk_off + (size_t)(y + 1) * bw + (x + 1);
+    float hv[18];
+#pragma unroll
+    for (int o = 0; o < 18; ++o) hv[o] = hist[(size_t)o * p.blk_per_frame];
+
+    float out[32];
+    float t1 = 0.0f, t2 = 0.0f, t3 = 0.0f, t4 = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 18; ++o) {
+        const float val = hv[o];
+        float h1 = val * n1; h1 = 0.2f < h1 ? 0.2f : h1;
+        float h2 = val * n2; h2 = 0.2f < h2 ? 0.2f : h2;
+        float h3 = val * n3; h3 = 0.2f < h3 ? 0.2f : h3;
+        float h4 = val * n4; h4 = 0.2f < h4 ? 0.2f : h4;
+        out[o] = (float)(0.5 * (double)(((h1 + h2) + h3) + h4));
+        t1 += h1; t2 += h2; t3 += h3; t4 += h4;
+    }
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+        const float sum = hv[o] + hv[o + 9];
+        float h1 = sum * n1; h1 = 0.2f < h1 ? 0.2f : h1;
+        float h2 = sum * n2; h2 = 0.2f < h2 ? 0.2f : h2;
+        float h3 = sum * n3; h3 = 0.2f < h3 ? 0.2f : h3;
+        float h4 = sum * n4; h4 = 0.2f < h4 ? 0.2f : h4;
+        out[18 + o] = (float)(0.5 * (double)(((h1 + h2) + h3) + h4));
+    }
+    out[27] = (float)(0.2357 * (double)t1);
+    out[28] = (float)(0.2357 * (double)t2);
+    out[29] = (float)(0.2357 * (double)t3);
+    out[30] = (float)(0.2357 * (double)t4);
+    out[31] = 0.0f;
+    float4 *dst = reinterpret_cast<float4 *>(p.feat + ((size_t)frame * p.cell_per_frame + idx) * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+}
+
+void launch_hog_feat(const HogParams &p, int nframes, hipStream_t s)
+{
+    if (p.cell_per_frame == 0) return;
+    dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), nframes);
+    hipLaunchKernelGGL(k_hog_feat, grid, dim3(256), 0, s, p);
+}
+
+}  // namespace pbd

@@ -1,0 +1,300 @@
+"""Host-side mirror of the reference's operator interface for the detection hot path, over the
+C ABI (include/pbd.h).  Same names and argument meaning as the reference:
+
+    IFeatures / HOGFeatures<T>            include/IFeatures.hpp:49-73, src/HOGFeatures.cpp
+    IConvolutionEngine / Spatial...       include/IConvolutionEngine.hpp:44-68, src/SpatialConvolutionEngine.cpp
+    DynamicProgram<T>                     include/DynamicProgram.hpp:74-75, src/DynamicProgram.cpp
+    PartsBasedDetector<T>                 include/PartsBasedDetector.hpp:152-175, src/PartsBasedDetector.cpp
+    Candidate                             include/Candidate.hpp:56-99
+
+Every compute call runs HIP kernels through libpbd_hip.so; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import PbdError
+from .model import FlatModel, Model
+
+
+@dataclass
+class Candidate:
+    """include/Candidate.hpp:56-80: part rectangles (x, y, w, h), confidences, component.
+    `frame`, `level`, `root` record where the candidate was back-tracked from."""
+
+    parts: np.ndarray
+    confidence: np.ndarray
+    component: int
+    frame: int = 0
+    level: int = 0
+    root: tuple = (0, 0)
+
+    def score(self) -> float:  # Candidate.hpp:82
+        return float(self.confidence[0]) if len(self.confidence) else float("-inf")
+
+    @staticmethod
+    def sort(candidates: List["Candidate"]) -> None:  # Candidate.hpp:91-99 (descending by score)
+        candidates.sort(key=lambda c: -c.score())
+
+
+class Handle:
+    """Owns a pbd_handle (one handle = one host thread = one GPU)."""
+
+    def __init__(self, model, device: int = 0, conv_mode: int = _lib.CONV_EXACT, max_batch: int = 1,
+                 max_candidates: int = 1 << 18, stream: Optional[int] = None, real_type: int = _lib.REAL_F32):
+        self.lib = _lib.load()
+        self.flat: FlatModel = model if isinstance(model, FlatModel) else model.flatten()
+        self._cm = _lib.c_model(self.flat)
+        cfg = _lib.CConfig(device, real_type, conv_mode, max_batch, max_candidates, stream)
+        h = C.c_void_p()
+        rc = self.lib.pbd_create(C.byref(self._cm), C.byref(cfg), C.byref(h))
+        if rc != _lib.PBD_OK:
+            raise PbdError(rc, self.lib.pbd_last_error(None).decode())
+        self.h = h
+        self.max_batch = max_batch
+        self.max_candidates = max_candidates
+        self.stride = self.lib.pbd_candidate_stride(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pbd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, allow=()):
+        if rc != _lib.PBD_OK and rc not in allow:
+            raise PbdError(rc, self.lib.pbd_last_error(self.h).decode())
+        return rc
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def plan(self, rows: int, cols: int):
+        n = C.c_int()
+        arrs = [np.zeros(_lib.MAX_LEVELS, np.int32) for _ in range(4)]
+        sc = np.zeros(_lib.MAX_LEVELS, np.float32)
+        self.check(self.lib.pbd_pyramid_plan(self.h, rows, cols, C.byref(n), *[_lib.ptr(a, C.c_int) for a in arrs],
+                                             _lib.ptr(sc, C.c_float)))
+        k = n.value
+        return {"nlevels": k, "img_rows": arrs[0][:k].copy(), "img_cols": arrs[1][:k].copy(),
+                "feat_rows": arrs[2][:k].copy(), "feat_cols": arrs[3][:k].copy(), "scales": sc[:k].copy()}
+
+    def unpack_candidates(self, buf: np.ndarray, n: int) -> List[Candidate]:
+        out = []
+        rec = buf[: n * self.stride].reshape(n, self.stride)
+        for r in rec:
+            npart = int(r[6])
+            conf = np.zeros(npart, np.float32)
+            conf[0] = r[5:6].view(np.float32)[0]
+            out.append(Candidate(parts=r[8:8 + 4 * npart].reshape(npart, 4).copy(), confidence=conf,
+                                 component=int(r[1]), frame=int(r[0]), level=int(r[2]), root=(int(r[3]), int(r[4]))))
+        return out
+
+    def profile(self, on: bool = True):
+        self.check(self.lib.pbd_profile_enable(self.h, int(on)))
+        self.check(self.lib.pbd_profile_reset(self.h))
+
+    def profile_read(self):
+        out = {}
+        for k, name in enumerate(_lib.KERNELS):
+            ms, n = C.c_double(), C.c_int()
+            self.check(self.lib.pbd_profile_read(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def get_stage(self, stage: int, frame: int, level: int, rows: int, cols: int):
+        planes = {_lib.STAGE_FEATURES: None, _lib.STAGE_RESPONSES: self.flat.nfilters,
+                  _lib.STAGE_ROOTV: self.flat.ncomponents, _lib.STAGE_ROOTI: self.flat.ncomponents}[stage]
+        if stage == _lib.STAGE_FEATURES:
+            dst = np.empty((rows, cols * self.flat.flen), np.float32)
+        elif stage == _lib.STAGE_ROOTI:
+            dst = np.empty((planes, rows, cols), np.int32)
+        else:
+            dst = np.empty((planes, rows, cols), np.float32)
+        self.check(self.lib.pbd_get_stage(self.h, stage, frame, level, dst.ctypes.data, dst.nbytes))
+        return dst
+
+
+class HOGFeatures:
+    """IFeatures (include/IFeatures.hpp:49-73) as implemented by HOGFeatures<float>."""
+
+    def __init__(self, handle: Handle):
+        self.hd = handle
+        self._scales = np.zeros(0, np.float32)
+
+    def binsize(self) -> int:
+        return self.hd.lib.pbd_binsize(self.hd.h)
+
+    def nscales(self) -> int:
+        return len(self._scales)
+
+    def scales(self) -> np.ndarray:
+        return self._scales
+
+    def pyramid(self, im: np.ndarray) -> List[np.ndarray]:
+        """pyramid(im, pyrafeatures): list of (H, W*flen) float32 maps, fine to coarse."""
+        if im.dtype != np.uint8:
+            # src/HOGFeatures.cpp:136-146 accepts 8U/16U/32F/64F; only 8-bit is built here
+            raise PbdError(-2, f"image dtype {im.dtype}: only uint8 is supported")
+        if im.ndim == 2:
+            im = im[:, :, None]
+        rows, cols, cn = im.shape
+        if not im.flags.c_contiguous and not (im.strides[2] == 1 and im.strides[1] == cn):
+            im = np.ascontiguousarray(im)
+        plan = self.hd.plan(rows, cols)
+        feats = [np.empty((int(r), int(c) * self.hd.flat.flen), np.float32)
+                 for r, c in zip(plan["feat_rows"], plan["feat_cols"])]
+        arr = _lib.ptr_array(feats)
+        self.hd.check(self.hd.lib.pbd_features_pyramid(self.hd.h, im.ctypes.data, rows, cols, cn, im.strides[0], 0, arr))
+        self._scales = plan["scales"]
+        return feats
+
+    def level_images(self, rows: int, cols: int, cn: int) -> List[np.ndarray]:
+        """the resampled pyramid images of the last pyramid()/detect() call (frame 0), for tests"""
+        plan = self.hd.plan(rows, cols)
+        out = []
+        for l in range(plan["nlevels"]):
+            img = np.empty((int(plan["img_rows"][l]), int(plan["img_cols"][l]), cn), np.uint8)
+            self.hd.check(self.hd.lib.pbd_get_pyramid_image(self.hd.h, 0, l, img.ctypes.data))
+            out.append(img)
+        return out
+
+
+class SpatialConvolutionEngine:
+    """IConvolutionEngine (include/IConvolutionEngine.hpp:44-68)."""
+
+    def __init__(self, handle: Handle):
+        self.hd = handle
+
+    def setFilters(self, filters: Sequence[np.ndarray]) -> None:
+        fl = [np.ascontiguousarray(f, np.float32) for f in filters]
+        ks = np.array([f.shape[0] for f in fl], np.int32)
+        arr = _lib.ptr_array(fl)
+        self.hd.check(self.hd.lib.pbd_conv_set_filters(self.hd.h, len(fl), arr, _lib.ptr(ks, C.c_int)))
+        self._nfilters = len(fl)
+
+    def pdf(self, features: Sequence[np.ndarray]) -> List[np.ndarray]:
+        """pdf(features, responses): responses[level] is (nfilters, H, W); responses[level][filter] as in the reference."""
+        flen = self.hd.flat.flen
+        feats = [np.ascontiguousarray(f, np.float32) for f in features]
+        rows = np.array([f.shape[0] for f in feats], np.int32)
+        cols = np.array([f.shape[1] // flen for f in feats], np.int32)
+        nf = getattr(self, "_nfilters", self.hd.flat.nfilters)
+        resp = [np.empty((nf, int(r), int(c)), np.float32) for r, c in zip(rows, cols)]
+        self.hd.check(self.hd.lib.pbd_conv_pdf(self.hd.h, len(feats), _lib.ptr_array(feats), _lib.ptr(rows, C.c_int),
+                                               _lib.ptr(cols, C.c_int), _lib.ptr_array(resp)))
+        return resp
+
+
+class DynamicProgram:
+    """DynamicProgram<float> (include/DynamicProgram.hpp:74-75)."""
+
+    def __init__(self, handle: Handle):
+        self.hd = handle
+
+    def min(self, scores: Sequence[np.ndarray]):
+        """min(parts, scores, Ix, Iy, Ik, rootv, rooti); scores[level] is (nfilters, H, W).
+        Returns per level: Ix, Iy, Ik as (nslots, H, W) int32 (slot = pbd_ptr_slot(c, part) + parent mixture),
+        rootv (ncomponents, H, W) float32, rooti (ncomponents, H, W) int32."""
+        sc = [np.ascontiguousarray(s, np.float32) for s in scores]
+        rows = np.array([s.shape[1] for s in sc], np.int32)
+        cols = np.array([s.shape[2] for s in sc], np.int32)
+        ns, nc = max(self.hd.flat.nslots, 1), self.hd.flat.ncomponents
+        Ix = [np.zeros((ns, int(r), int(c)), np.int32) for r, c in zip(rows, cols)]
+        Iy = [np.zeros((ns, int(r), int(c)), np.int32) for r, c in zip(rows, cols)]
+        Ik = [np.zeros((ns, int(r), int(c)), np.int32) for r, c in zip(rows, cols)]
+        rootv = [np.empty((nc, int(r), int(c)), np.float32) for r, c in zip(rows, cols)]
+        rooti = [np.empty((nc, int(r), int(c)), np.int32) for r, c in zip(rows, cols)]
+        self.hd.check(self.hd.lib.pbd_dp_min(self.hd.h, len(sc), _lib.ptr(rows, C.c_int), _lib.ptr(cols, C.c_int),
+                                             _lib.ptr_array(sc), _lib.ptr_array(Ix), _lib.ptr_array(Iy),
+                                             _lib.ptr_array(Ik), _lib.ptr_array(rootv), _lib.ptr_array(rooti)))
+        return Ix, Iy, Ik, rootv, rooti
+
+    def argmin(self, scales: np.ndarray, capacity: Optional[int] = None) -> List[Candidate]:
+        """argmin(parts, rootv, rooti, scales, Ix, Iy, Ik, candidates) on the result of the last min()."""
+        cap = capacity or self.hd.max_candidates
+        buf = np.zeros(cap * self.hd.stride, np.int32)
+        n = C.c_int()
+        sc = np.ascontiguousarray(scales, np.float32)
+        self.hd.check(self.hd.lib.pbd_dp_argmin(self.hd.h, _lib.ptr(sc, C.c_float), buf.ctypes.data, cap, C.byref(n)))
+        return self.hd.unpack_candidates(buf, n.value)
+
+
+class PartsBasedDetector:
+    """PartsBasedDetector<float> (include/PartsBasedDetector.hpp:152-175)."""
+
+    def __init__(self, device: int = 0, conv_mode: int = _lib.CONV_EXACT, max_batch: int = 1,
+                 max_candidates: int = 1 << 18, stream: Optional[int] = None):
+        self._kw = dict(device=device, conv_mode=conv_mode, max_batch=max_batch, max_candidates=max_candidates,
+                        stream=stream)
+        self.hd: Optional[Handle] = None
+        self._name = ""
+
+    def name(self) -> str:
+        return self._name
+
+    def distributeModel(self, model: Model) -> None:
+        """src/PartsBasedDetector.cpp:102-127: creates the feature / convolution engines and the DP."""
+        if self.hd is not None:
+            self.hd.close()
+        self.hd = Handle(model, **self._kw)
+        self._name = getattr(model, "name", "")
+        self.features_ = HOGFeatures(self.hd)
+        self.convolution_engine_ = SpatialConvolutionEngine(self.hd)
+        self.dp_ = DynamicProgram(self.hd)
+
+    def _need(self):
+        if self.hd is None:
+            raise PbdError(-5, "detect() before distributeModel()")
+
+    def detect(self, im: np.ndarray, depth: Optional[np.ndarray] = None, capacity: Optional[int] = None) -> List[Candidate]:
+        """detect(im[, depth], candidates); `depth` is ignored exactly as in the reference (:91-93)."""
+        self._need()
+        if im.dtype != np.uint8:
+            raise PbdError(-2, f"image dtype {im.dtype}: only uint8 is supported")
+        if im.ndim == 2:
+            im = im[:, :, None]
+        if not (im.strides[2] == 1 and im.strides[1] == im.shape[2]):
+            im = np.ascontiguousarray(im)
+        rows, cols, cn = im.shape
+        cap = capacity or self.hd.max_candidates
+        buf = np.zeros(cap * self.hd.stride, np.int32)
+        n = C.c_int()
+        self.hd.check(self.hd.lib.pbd_detect(self.hd.h, im.ctypes.data, rows, cols, cn, im.strides[0], buf.ctypes.data,
+                                             cap, C.byref(n)))
+        self.features_._scales = self.hd.plan(rows, cols)["scales"]
+        return self.hd.unpack_candidates(buf, n.value)
+
+    def detect_batch(self, frames: Sequence[np.ndarray], capacity: Optional[int] = None) -> List[Candidate]:
+        self._need()
+        fr = [np.ascontiguousarray(f if f.ndim == 3 else f[:, :, None], np.uint8) for f in frames]
+        rows, cols, cn = fr[0].shape
+        assert all(f.shape == fr[0].shape for f in fr), "a batch holds equally sized frames"
+        cap = capacity or self.hd.max_candidates
+        buf = np.zeros(cap * self.hd.stride, np.int32)
+        n = C.c_int()
+        self.hd.check(self.hd.lib.pbd_detect_batch(self.hd.h, len(fr), _lib.ptr_array(fr), rows, cols, cn, cols * cn,
+                                                   buf.ctypes.data, cap, C.byref(n)))
+        return self.hd.unpack_candidates(buf, n.value)
+
+    def detect_batch_device(self, d_frames_ptr: int, nframes: int, rows: int, cols: int, cn: int,
+                            capacity: Optional[int] = None, raw: bool = False):
+        """frames already resident in device memory (e.g. a torch uint8 tensor's data_ptr())."""
+        self._need()
+        cap = capacity or self.hd.max_candidates
+        if not hasattr(self, "_buf") or self._buf.size < cap * self.hd.stride:
+            self._buf = np.zeros(cap * self.hd.stride, np.int32)
+        n = C.c_int()
+        self.hd.check(self.hd.lib.pbd_detect_batch_device(self.hd.h, nframes, d_frames_ptr, rows, cols, cn,
+                                                          self._buf.ctypes.data, cap, C.byref(n)))
+        if raw:
+            return self._buf, n.value
+        return self.hd.unpack_candidates(self._buf, n.value)

@@ -1,0 +1,226 @@
+"""GPU parity tests: every stage of the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  Bars: integer/index outputs and (in EXACT convolution mode) float outputs
+bit-exact; FMA convolution mode within 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from partsbaseddetector_amd import synth
+from partsbaseddetector_amd import model as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def det_mod():
+    from partsbaseddetector_amd import detector
+    return detector
+
+
+def _handle(det_mod, model, **kw):
+    return det_mod.Handle(model, device=0, **kw)
+
+
+def _cand_key(c):
+    return (c["level"], c["component"], c["root_y"], c["root_x"])
+
+
+def _compare_candidates(got, want):
+    assert len(got) == len(want), (len(got), len(want))
+    for g, w in zip(got, want):
+        assert (g.level, g.component, g.root[1], g.root[0]) == _cand_key(w)
+        assert np.array_equal(g.parts, w["parts"]), (g.parts, w["parts"])
+        assert np.float32(g.score()) == np.float32(w["score"])
+
+
+@pytest.mark.parametrize("shape,cn", [((96, 80), 3), ((123, 157), 3), ((97, 131), 1), ((240, 320), 3)])
+def test_pyramid_images_and_features(det_mod, oracle, shape, cn):
+    model = M.synthetic_tiny_model()
+    flat = model.flatten()
+    hd = _handle(det_mod, flat)
+    feats_eng = det_mod.HOGFeatures(hd)
+    im = synth.synthetic_frame(11, shape[0], shape[1], cn)
+    got = feats_eng.pyramid(im)
+    want, scales = oracle.features_pyramid(flat, im)
+    assert len(got) == len(want) == feats_eng.nscales()
+    assert np.array_equal(feats_eng.scales(), scales)
+    imgs_want, _ = oracle.pyramid_images(im, flat.sbin, flat.interval)
+    imgs_got = feats_eng.level_images(shape[0], shape[1], cn)
+    for l, (a, b) in enumerate(zip(imgs_got, imgs_want)):
+        assert a.shape == b.shape, (l, a.shape, b.shape)
+        assert np.array_equal(a, b), f"pyramid image level {l}: {np.count_nonzero(a != b)} pixels differ"
+    for l, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape, (l, a.shape, b.shape)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
+            f"features level {l}: {np.count_nonzero(a != b)} of {a.size} differ, max {np.abs(a - b).max()}"
+    hd.close()
+
+
+def test_features_noise_and_constant_frames(det_mod, oracle):
+    flat = M.synthetic_tiny_model().flatten()
+    hd = _handle(det_mod, flat)
+    eng = det_mod.HOGFeatures(hd)
+    for kind in ("noise", "constant"):
+        im = synth.synthetic_frame(3, 90, 110, 3, kind=kind)
+        got = eng.pyramid(im)
+        want, _ = oracle.features_pyramid(flat, im)
+        for a, b in zip(got, want):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        if kind == "constant":
+            assert all(not a.any() for a in got)   # zero gradients -> all 32 channels exactly 0
+    hd.close()
+
+
+def test_strided_image(det_mod, oracle):
+    flat = M.synthetic_tiny_model().flatten()
+    hd = _handle(det_mod, flat)
+    eng = det_mod.HOGFeatures(hd)
+    big = synth.synthetic_frame(9, 120, 200, 3)
+    view = big[:, 20:150]          # non-contiguous rows (cv::Mat ROI)
+    got = eng.pyramid(view)
+    want, _ = oracle.features_pyramid(flat, np.ascontiguousarray(view))
+    for a, b in zip(got, want):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    hd.close()
+
+
+@pytest.mark.parametrize("mode", ["exact", "fma"])
+def test_conv_pdf(det_mod, oracle, mode):
+    from partsbaseddetector_amd import _lib
+    flat = M.synthetic_tiny_model().flatten()
+    hd = _handle(det_mod, flat, conv_mode=_lib.CONV_EXACT if mode == "exact" else _lib.CONV_FMA)
+    conv = det_mod.SpatialConvolutionEngine(hd)
+    rng = np.random.default_rng(5)
+    # ragged levels incl. maps smaller than the filter and one empty level
+    dims = [(37, 45), (8, 33), (3, 2), (1, 1), (0, 5), (12, 70)]
+    feats = [(rng.random((h, w * 32), dtype=np.float32) * 0.4) for h, w in dims]
+    for f in feats:
+        if f.size:
+            f.reshape(f.shape[0], -1, 32)[:, :, 31] = 0.0
+    feats[1].reshape(8, 33, 32)[:, :, 31] = 0.3   # a non-zero last channel inside the image
+    got = conv.pdf(feats)
+    for (h, w), f, g in zip(dims, feats, got):
+        assert g.shape == (flat.nfilters, h, w)
+        if h * w == 0:
+            continue
+        want = oracle.responses(flat, f)
+        if mode == "exact":
+            assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), \
+                f"{h}x{w}: {np.count_nonzero(g != want)} differ, max {np.abs(g - want).max()}"
+        else:
+            assert np.abs(g - want).max() <= 1e-4
+    hd.close()
+
+
+def test_conv_set_filters_replaces_model_filters(det_mod, oracle):
+    flat = M.synthetic_tiny_model().flatten()
+    hd = _handle(det_mod, flat)
+    conv = det_mod.SpatialConvolutionEngine(hd)
+    rng = np.random.default_rng(6)
+    filters = [rng.standard_normal((5, 5 * 32)).astype(np.float32) * 0.1 for _ in range(11)]   # 11: not a multiple of 8
+    conv.setFilters(filters)
+    feat = rng.random((20, 41 * 32), dtype=np.float32)
+    got = conv.pdf([feat])[0]
+    assert got.shape == (11, 20, 41)
+    for f in range(11):
+        want = oracle.conv(feat, filters[f])
+        assert np.array_equal(got[f].view(np.uint32), want.view(np.uint32))
+    hd.close()
+
+
+@pytest.mark.parametrize("which", ["tiny", "tiny_plain", "face", "person_small"])
+def test_dp_min(det_mod, oracle, which):
+    if which == "tiny":
+        model = M.synthetic_tiny_model(linear_def=True)
+    elif which == "tiny_plain":
+        model = M.synthetic_tiny_model(linear_def=False)
+    elif which == "face":
+        model = M.synthetic_face_model(nparts=9, ncomponents=2)
+    else:
+        model = M.synthetic_person_model()
+    flat = model.flatten()
+    hd = _handle(det_mod, flat)
+    dp = det_mod.DynamicProgram(hd)
+    rng = np.random.default_rng(8)
+    dims = [(21, 30), (9, 7), (1, 6), (5, 1)] if which != "person_small" else [(30, 41), (6, 5)]
+    scores = [rng.standard_normal((flat.nfilters, h, w)).astype(np.float32) for h, w in dims]
+    Ix, Iy, Ik, rootv, rooti = dp.min(scores)
+    for l, s in enumerate(scores):
+        for c in range(flat.ncomponents):
+            oIx, oIy, oIk, orv, ori = oracle.dp_min(flat, c, s)
+            assert np.array_equal(rootv[l][c].view(np.uint32), orv.view(np.uint32)), (l, c, np.abs(rootv[l][c] - orv).max())
+            assert np.array_equal(rooti[l][c], ori)
+            p0, p1 = flat.part_offset[c], flat.part_offset[c + 1]
+            for gp in range(p0 + 1, p1):
+                par = p0 + flat.parentid[gp]
+                L = flat.mix_offset[par + 1] - flat.mix_offset[par]
+                for m in range(L):
+                    sl = flat.ptr_slot[gp] + m
+                    assert np.array_equal(Ik[l][sl], oIk[sl]), (l, c, gp, m)
+                    assert np.array_equal(Ix[l][sl], oIx[sl]), (l, c, gp, m)
+                    assert np.array_equal(Iy[l][sl], oIy[sl]), (l, c, gp, m)
+    hd.close()
+
+
+@pytest.mark.parametrize("which,shape,thresh", [("tiny", (96, 128), 0.6), ("tiny", (150, 101), 0.2),
+                                                 ("face", (240, 320), None), ("person", (160, 120), None)])
+def test_detect_end_to_end(det_mod, oracle, which, shape, thresh):
+    if which == "tiny":
+        model = M.synthetic_tiny_model(thresh=thresh)
+    elif which == "face":
+        model = M.synthetic_face_model(thresh=5.8)
+    else:
+        model = M.synthetic_person_model(thresh=17.9)
+    flat = model.flatten()
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    im = synth.synthetic_frame(21, shape[0], shape[1], 3)
+    got = det.detect(im)
+    want = oracle.detect(flat, im)
+    assert len(want) > 0
+    _compare_candidates(got, want)
+    # staged read-back of the same run: responses and root scores, bit-exact
+    feats, _ = oracle.features_pyramid(flat, im)
+    for l in (0, len(feats) - 1):
+        H, W = feats[l].shape[0], feats[l].shape[1] // 32
+        r = det.hd.get_stage(1, 0, l, H, W)
+        want_r = oracle.responses(flat, feats[l])
+        assert np.array_equal(r.view(np.uint32), want_r.view(np.uint32))
+    det.hd.close()
+
+
+def test_detect_batch_equals_single_calls(det_mod, oracle):
+    model = M.synthetic_tiny_model(thresh=0.5)
+    det = det_mod.PartsBasedDetector(device=0, max_batch=5)
+    det.distributeModel(model)
+    frames = [synth.synthetic_frame(30 + i, 100, 140, 3) for i in range(5)]
+    batch = det.detect_batch(frames)
+    off = 0
+    for i, f in enumerate(frames):
+        single = det.detect(f)
+        mine = [c for c in batch if c.frame == i]
+        assert len(mine) == len(single)
+        for a, b in zip(mine, single):
+            assert (a.level, a.component, a.root) == (b.level, b.component, b.root)
+            assert np.array_equal(a.parts, b.parts) and a.score() == b.score()
+        off += len(mine)
+    assert off == len(batch)
+    det.hd.close()
+
+
+def test_errors(det_mod):
+    from partsbaseddetector_amd._lib import PbdError
+    model = M.synthetic_tiny_model(thresh=0.5)
+    det = det_mod.PartsBasedDetector(device=0)
+    with pytest.raises(PbdError):
+        det.detect(np.zeros((100, 100, 3), np.uint8))          # before distributeModel
+    det.distributeModel(model)
+    with pytest.raises(PbdError):
+        det.detect(np.zeros((10, 10, 3), np.uint8))            # too small for one octave
+    with pytest.raises(PbdError):
+        det.detect(np.zeros((100, 100, 3), np.float32))        # unsupported depth
+    with pytest.raises(PbdError):
+        det.detect(np.zeros((100, 100, 2), np.uint8))          # channels must be 1 or 3
+    with pytest.raises(PbdError) as e:
+        det.detect(synth.synthetic_frame(1, 100, 100), capacity=1)   # capacity overflow is reported
+    assert e.value.code == -4
+    det.hd.close()
