@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpbd_hip.so")
+LIB_PATH = os.environ.get("PBD_LIB", os.path.join(HERE, "libpbd_hip.so"))
 MAX_LEVELS = 128
 
 PBD_OK = 0

@@ -109,11 +109,14 @@ struct Plan {
     DevTable<ResizeTabY> d_taby;
     DevTable<ConvTile> d_tiles;
     DevTable<int> d_row2level, d_rowoff, d_col2level, d_coloff;
+    DevTable<long long> d_stk_row_off, d_stk_col_off;
+    long long stk_per_jf = 0;
     DevTable<float> d_scales;
     void release()
     {
         d_lv.release(); d_tabx.release(); d_taby.release(); d_tiles.release();
         d_row2level.release(); d_rowoff.release(); d_col2level.release(); d_coloff.release(); d_scales.release();
+        d_stk_row_off.release(); d_stk_col_off.release();
     }
     ~Plan() { release(); }
 };
@@ -193,7 +196,7 @@ struct pbd_handle {
 
     // workspace
     DevBuf frames, pyr, hist, norm, feat, resp, msg, Ix, Iy, Ik, rootv, rooti;
-    DevBuf tmp, dt, IxRaw, IyRaw, stk_v, stk_z, stk_s, cand, count, scales_tmp;
+    DevBuf tmp, dt, IxRaw, IyRaw, stk, cand, count, scales_tmp;
     std::vector<int32_t> cand_host;
 
     Prof prof;
@@ -253,6 +256,25 @@ void finish_plan_tables(Plan &P)
     P.nrows_flat = (int)row2level.size();
     P.ncols_flat = (int)col2level.size();
     P.ntiles = (int)tiles.size();
+    // wave-private stack regions: a wave of 64 flat rows (columns) needs 64 x (longest row in the wave)
+    // entries; levels are ordered large to small, but take the maximum to be safe
+    std::vector<long long> srow, scol;
+    long long tot_r = 0, tot_c = 0;
+    for (int w0 = 0; w0 < P.nrows_flat; w0 += 64) {
+        int mx = 0;
+        for (int r = w0; r < std::min(w0 + 64, P.nrows_flat); ++r) mx = std::max(mx, P.lv[row2level[r]].cols);
+        srow.push_back(tot_r);
+        tot_r += 64LL * mx;
+    }
+    for (int w0 = 0; w0 < P.ncols_flat; w0 += 64) {
+        int mx = 0;
+        for (int c = w0; c < std::min(w0 + 64, P.ncols_flat); ++c) mx = std::max(mx, P.lv[col2level[c]].rows);
+        scol.push_back(tot_c);
+        tot_c += 64LL * mx;
+    }
+    P.stk_per_jf = std::max(tot_r, tot_c);
+    (void)P.d_stk_row_off.upload(srow);
+    (void)P.d_stk_col_off.upload(scol);
     (void)P.d_lv.upload(P.lv);
     (void)P.d_tiles.upload(tiles);
     (void)P.d_row2level.upload(row2level);
@@ -499,10 +521,10 @@ int build_model(pbd_handle *h, const pbd_model *m)
                     j.osx = h->anchors[(size_t)d * 2]; j.osy = h->anchors[(size_t)d * 2 + 1];
                     g.jobs.push_back(j);
                 }
-                for (int pm = 0; pm < L; ++pm) {
+                {
                     CombineJob cj{};
-                    cj.job_begin = job_begin; cj.nmix = K; cj.slot = h->ptr_slot[gp] + pm;
-                    for (int mm = 0; mm < K; ++mm) cj.bias_off[mm] = h->biasid[h->mix_offset[gp] + mm] + pm;
+                    cj.job_begin = job_begin; cj.nmix = K; cj.npar = L; cj.slot = h->ptr_slot[gp];
+                    for (int mm = 0; mm < K; ++mm) cj.bias_off[mm] = h->biasid[h->mix_offset[gp] + mm];
                     g.cjobs.push_back(cj);
                 }
             }
@@ -622,15 +644,14 @@ int run_dp(pbd_handle *h, Plan &P, int nframes)
     // scratch for one chunk of frames: bounded so that a batch does not multiply the DT intermediates
     const size_t per_frame = cpf * std::max(h->JGmax, 1);
     int chunk = nframes;
-    const size_t budget = (size_t)6 << 30;   // bytes of scratch across the seven arrays (22 B / cell-job)
-    while (chunk > 1 && per_frame * chunk * 22 > budget) chunk = (chunk + 1) / 2;
+    const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
+    const size_t budget = (size_t)8 << 30;   // bytes of scratch per chunk (14 B / cell-job + 12 B / stack entry)
+    while (chunk > 1 && (per_frame * 14 + stk_per_frame * 12) * chunk > budget) chunk = (chunk + 1) / 2;
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
     HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
-    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
+    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int), 16)));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
-    HIPCHK(h, h->stk_v.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
-    HIPCHK(h, h->stk_z.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
-    HIPCHK(h, h->stk_s.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
+    HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * 12, 16)));
 
     DpParams dp{};
     dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC;
@@ -638,8 +659,9 @@ int run_dp(pbd_handle *h, Plan &P, int nframes)
     dp.resp = h->resp.as<float>(); dp.msg = h->msg.as<float>();
     dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
     dp.tmp = h->tmp.as<float>(); dp.dt = h->dt.as<float>();
-    dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
-    dp.stk_v = h->stk_v.as<int16_t>(); dp.stk_z = h->stk_z.as<float>(); dp.stk_s = h->stk_s.as<float>();
+    dp.IxRaw32 = h->IxRaw.as<int>(); dp.IyRaw = h->IyRaw.as<int16_t>();
+    dp.stk = h->stk.p; dp.stk_per_jf = P.stk_per_jf;
+    dp.stk_row_off = P.d_stk_row_off.d; dp.stk_col_off = P.d_stk_col_off.d;
     dp.child_slots = h->d_child_slots.d; dp.biasw = h->d_biasw.d;
     dp.row2level = P.d_row2level.d; dp.rowoff = P.d_rowoff.d; dp.col2level = P.d_col2level.d; dp.coloff = P.d_coloff.d;
     dp.nrows_flat = P.nrows_flat; dp.ncols_flat = P.ncols_flat;
@@ -804,7 +826,7 @@ void pbd_destroy(pbd_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->prof.release();
     for (DevBuf *b : {&h->frames, &h->pyr, &h->hist, &h->norm, &h->feat, &h->resp, &h->msg, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
-                      &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk_v, &h->stk_z, &h->stk_s, &h->cand, &h->count,
+                      &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();
     h->d_wts.release(); h->d_biasw.release(); h->d_child_slots.release(); h->d_walk_off.release();

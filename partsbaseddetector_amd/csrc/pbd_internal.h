@@ -43,11 +43,12 @@ struct DtJob {
 };
 
 // combine job = (part, parent mixture) of one tree-depth group
-struct CombineJob {
+struct CombineJob {           // one per part of the group (all parent mixtures)
     int job_begin;            // first DtJob (index within the group) of this part
     int nmix;                 // child mixtures K
-    int slot;                 // back-pointer / message slot = ptr_slot[part] + parent mixture
-    int bias_off[8];          // biasid[part][mm] + parent mixture, mm < K   (K <= 8)
+    int npar;                 // parent mixtures L
+    int slot;                 // back-pointer / message slot of parent mixture 0 = ptr_slot[part]
+    int bias_off[8];          // biasid[part][mm], mm < K (add the parent mixture)   (K <= 8)
 };
 
 struct RootJob {              // one per component
@@ -115,8 +116,11 @@ struct DpParams {
     // group scratch, indexed by chunk-local frame
     int JG;                       // jobs in this group
     float *tmp, *dt;              // [chunk][cell_per_frame*JG]
-    int16_t *IxRaw, *IyRaw;
-    int16_t *stk_v; float *stk_z, *stk_s;
+    int *IxRaw32; int16_t *IyRaw;
+    void *stk;                    // [chunk][JG][stk_per_jf] 12-byte entries, wave-private, lane-interleaved
+    long long stk_per_jf;         // entries per (job, frame)
+    const long long *stk_row_off; // per rows-pass wave (64 flat rows): first entry
+    const long long *stk_col_off; // per columns-pass wave
     const DtJob *jobs;
     const int *child_slots;
     const CombineJob *cjobs;

@@ -36,71 +36,151 @@ __device__ __forceinline__ float dt_input(const float *resp_plane, const float *
     return v;
 }
 
-// one 1-D transform; src/dst/ptr/stack are strided views (element i at base[i*stride])
-struct StackRef {
-    int16_t *v; float *z; float *s; size_t stride;
-};
+// ------------------------------------------------------------------------------------------------
+// One 1-D transform per thread, streamed in chunks of CH elements.
+//   * the envelope's top entry (v[k], z[k], src[v[k]]) lives in registers; pushes are fire-and-forget
+//     stores, only pops read memory;
+//   * the stack of a wave is wave-private and lane-interleaved ([k][lane], 12-byte entries), so the hot
+//     top-of-stack lines of all resident waves fit in L2;
+//   * source values are prefetched one chunk ahead (wide per-lane loads in the rows pass, coalesced
+//     loads in the columns pass) and results leave in whole chunks.
+// The arithmetic and control flow per element are exactly computeRow's (DistanceTransform.hpp:152-182).
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(4))) StkEntry { float z; float s; int v; };
 
-template <typename SrcFn>
-__device__ __forceinline__ void dt_1d(SrcFn src, int N, double a, double b, int os, StackRef st,
-                                      float *dst, int16_t *ptr, size_t ostride)
+constexpr int kDtCH = 8;
+
+template <class LoadChunk, class StoreChunk>
+__device__ __forceinline__ void dt_stream(int N, double a, double b, int os, StkEntry *stk, LoadChunk load, StoreChunk store)
 {
-    // envelope construction, include/DistanceTransform.hpp:156-170; top of stack cached in registers
-    int k = 0;
-    int vk = 0;
-    float zk = -INFINITY;
-    float sk = src(0);
-    st.v[0] = 0; st.z[0] = zk; st.s[0] = sk;
-    for (int q = 1; q < N; ++q) {
-        const float sq = src(q);
-        float s = quad_isect(a, b, vk, q, sk, sq);
-        while (s <= zk && k > 0) {
-            --k;
-            vk = st.v[k * st.stride]; zk = st.z[k * st.stride]; sk = st.s[k * st.stride];
-            s = quad_isect(a, b, vk, q, sk, sq);
+    constexpr int CH = kDtCH;
+    float cur[CH], nxt[CH];
+    load(0, cur);
+    int k = 0, vk = 0;
+    float zk = -INFINITY, sk = cur[0];
+    stk[0] = StkEntry{zk, sk, 0};
+    for (int q0 = 0; q0 < N; q0 += CH) {
+        if (q0 + CH < N) load(q0 + CH, nxt);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int q = q0 + i;
+            if (q >= 1 && q < N) {
+                const float sq = cur[i];
+                float s = quad_isect(a, b, vk, q, sk, sq);
+                while (s <= zk && k > 0) {
+                    --k;
+                    const StkEntry e = stk[(size_t)k * 64];
+                    vk = e.v; zk = e.z; sk = e.s;
+                    s = quad_isect(a, b, vk, q, sk, sq);
+                }
+                ++k;
+                vk = q; zk = s; sk = sq;
+                stk[(size_t)k * 64] = StkEntry{zk, sk, vk};
+            }
         }
-        ++k;
-        vk = q; zk = s; sk = sq;
-        st.v[k * st.stride] = (int16_t)vk; st.z[k * st.stride] = zk; st.s[k * st.stride] = sk;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
     }
     const int ktop = k;
-    // read-out, :172-178
     k = 0;
-    vk = 0; sk = st.s[0];
-    float znext = (ktop >= 1) ? st.z[st.stride] : INFINITY;
-    for (int q = 0; q < N; ++q) {
-        while (znext < (float)os) {
-            ++k;
-            vk = st.v[k * st.stride]; sk = st.s[k * st.stride];
-            znext = (k + 1 <= ktop) ? st.z[(size_t)(k + 1) * st.stride] : INFINITY;
+    {
+        const StkEntry e = stk[0];
+        vk = e.v; sk = e.s;
+    }
+    float znext = INFINITY, snext = 0.f;
+    int vnext = 0;
+    if (ktop >= 1) {
+        const StkEntry e = stk[64];
+        znext = e.z; snext = e.s; vnext = e.v;
+    }
+    for (int q0 = 0; q0 < N; q0 += CH) {
+        float out[CH];
+        int ptr[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            out[i] = 0.f; ptr[i] = 0;
+            if (q0 + i < N) {
+                while (znext < (float)os) {
+                    ++k;
+                    vk = vnext; sk = snext;
+                    if (k + 1 <= ktop) {
+                        const StkEntry e = stk[(size_t)(k + 1) * 64];
+                        znext = e.z; snext = e.s; vnext = e.v;
+                    } else {
+                        znext = INFINITY;
+                    }
+                }
+                out[i] = quad_val(a, b, os - vk, sk);
+                ptr[i] = vk;
+                ++os;
+            }
         }
-        dst[q * ostride] = quad_val(a, b, os - vk, sk);
-        ptr[q * ostride] = (int16_t)vk;
-        ++os;
+        store(q0, out, ptr);
     }
 }
 
-// ---- rows pass: thread = (flat row, job, frame) ------------------------------------------------
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
+
+// ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
 __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.nrows_flat) return;
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    const bool active = r < p.nrows_flat;
+    const int rr = active ? r : p.nrows_flat - 1;
     const int j = blockIdx.y, fl = blockIdx.z, frame = p.frame0 + fl;
-    const int l = p.row2level[r];
+    const int l = p.row2level[rr];
     const LevelDesc d = p.lv[l];
-    const int y = r - p.rowoff[l];
+    const int y = rr - p.rowoff[l];
     const int W = d.cols;
     const size_t HW = (size_t)d.rows * W;
     const DtJob job = p.jobs[j];
-    const float *resp_plane = p.resp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)job.filter * HW;
-    const float *msg_base = p.msg + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS;
-    const size_t sbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y * W;
-    StackRef st{p.stk_v + sbase, p.stk_z + sbase, p.stk_s + sbase, 1};
+    const float *src = p.resp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)job.filter * HW + (size_t)y * W;
+    const float *msg_row = p.msg + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + (size_t)y * W;
+    const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y * W;
+    float *tmp = p.tmp + obase;
+    int *ixr = p.IxRaw32 + obase;
+    StkEntry *stk = reinterpret_cast<StkEntry *>(p.stk) +
+                    ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[blockIdx.x]) + threadIdx.x;
     const int *cs = p.child_slots;
     const int cb = job.child_begin, ce = job.child_end;
-    const size_t rowoff = (size_t)y * W;
-    dt_1d([&](int q) { return dt_input(resp_plane, msg_base, HW, rowoff + q, cs, cb, ce); },
-          W, job.ax, job.bx, job.osx, st, p.tmp + sbase, p.IxRaw + sbase, 1);
+    const int N = active ? W : 0;
+    if (N == 0) return;
+    auto load = [&](int q0, float *buf) {
+        if (q0 + kDtCH <= N) {
+            const v4f_u a0 = *reinterpret_cast<const v4f_u *>(src + q0), a1 = *reinterpret_cast<const v4f_u *>(src + q0 + 4);
+            buf[0] = a0.x; buf[1] = a0.y; buf[2] = a0.z; buf[3] = a0.w; buf[4] = a1.x; buf[5] = a1.y; buf[6] = a1.z; buf[7] = a1.w;
+            for (int c = cb; c < ce; ++c) {   // children's messages, descending child order
+                const float *m = msg_row + (size_t)cs[c] * HW + q0;
+                const v4f_u m0 = *reinterpret_cast<const v4f_u *>(m), m1 = *reinterpret_cast<const v4f_u *>(m + 4);
+                buf[0] = buf[0] + m0.x; buf[1] = buf[1] + m0.y; buf[2] = buf[2] + m0.z; buf[3] = buf[3] + m0.w;
+                buf[4] = buf[4] + m1.x; buf[5] = buf[5] + m1.y; buf[6] = buf[6] + m1.z; buf[7] = buf[7] + m1.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kDtCH; ++i) {
+                float v = 0.f;
+                if (q0 + i < N) {
+                    v = src[q0 + i];
+                    for (int c = cb; c < ce; ++c) v = v + msg_row[(size_t)cs[c] * HW + q0 + i];
+                }
+                buf[i] = v;
+            }
+        }
+    };
+    auto store = [&](int q0, const float *out, const int *ptr) {
+        if (q0 + kDtCH <= N) {
+            *reinterpret_cast<v4f_u *>(tmp + q0) = v4f_u{out[0], out[1], out[2], out[3]};
+            *reinterpret_cast<v4f_u *>(tmp + q0 + 4) = v4f_u{out[4], out[5], out[6], out[7]};
+            *reinterpret_cast<v4i_u *>(ixr + q0) = v4i_u{ptr[0], ptr[1], ptr[2], ptr[3]};
+            *reinterpret_cast<v4i_u *>(ixr + q0 + 4) = v4i_u{ptr[4], ptr[5], ptr[6], ptr[7]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < kDtCH; ++i)
+                if (q0 + i < N) { tmp[q0 + i] = out[i]; ixr[q0 + i] = ptr[i]; }
+        }
+    };
+    dt_stream(N, job.ax, job.bx, job.osx, stk, load, store);
 }
 
 void launch_dt_rows(const DpParams &p, int nframes, hipStream_t s)
@@ -113,7 +193,7 @@ void launch_dt_rows(const DpParams &p, int nframes, hipStream_t s)
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
 __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
 {
-    const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cidx = blockIdx.x * 64 + threadIdx.x;
     if (cidx >= p.ncols_flat) return;
     const int j = blockIdx.y, fl = blockIdx.z;
     const int l = p.col2level[cidx];
@@ -122,12 +202,22 @@ __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
     const int H = d.rows, W = d.cols;
     const size_t HW = (size_t)H * W;
     const DtJob job = p.jobs[j];
-    const size_t base = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
-    const float *tmp = p.tmp + base + x;
-    // column x's stack lives in the [k][x] plane of the same job-sized scratch: entry k at k*W + x
-    StackRef st{p.stk_v + base + x, p.stk_z + base + x, p.stk_s + base + x, (size_t)W};
-    dt_1d([&](int q) { return tmp[(size_t)q * W]; }, H, job.ay, job.by, job.osy, st, p.dt + base + x, p.IyRaw + base + x,
-          (size_t)W);
+    const size_t base = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + x;
+    const float *tmp = p.tmp + base;
+    float *dt = p.dt + base;
+    int16_t *iyr = p.IyRaw + base;
+    StkEntry *stk = reinterpret_cast<StkEntry *>(p.stk) +
+                    ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[blockIdx.x]) + threadIdx.x;
+    auto load = [&](int q0, float *buf) {
+#pragma unroll
+        for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmp[(size_t)(q0 + i) * W] : 0.f;
+    };
+    auto store = [&](int q0, const float *out, const int *ptr) {
+#pragma unroll
+        for (int i = 0; i < kDtCH; ++i)
+            if (q0 + i < H) { dt[(size_t)(q0 + i) * W] = out[i]; iyr[(size_t)(q0 + i) * W] = (int16_t)ptr[i]; }
+    };
+    dt_stream(H, job.ay, job.by, job.osy, stk, load, store);
 }
 
 void launch_dt_cols(const DpParams &p, int nframes, hipStream_t s)
@@ -137,7 +227,7 @@ void launch_dt_cols(const DpParams &p, int nframes, hipStream_t s)
     hipLaunchKernelGGL(k_dt_cols, grid, dim3(64), 0, s, p);
 }
 
-// ---- combine: thread = cell; block.y = (part, parent mixture) job ---------------------------------
+// ---- combine: thread = cell of one part (block.y), all parent mixtures -------------------------------
 // weighted[mm] = score_dt[mm] + bias(mm)[m]; reduceMax (strict >, first wins, start -inf; K==1 copies);
 // Ix/Iy picked from the winning mixture, with the reference's Iy composition
 // Iy[y][x] = IyRaw[y][Ix[y][x]] (include/DistanceTransform.hpp:233-244); message = max value.
@@ -147,7 +237,6 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
     if (idx >= p.cell_per_frame) return;
     const int fl = blockIdx.z, frame = p.frame0 + fl;
     const CombineJob cj = p.cjobs[blockIdx.y];
-    // level lookup by binary search on cell_off
     int lo = 0, hi = p.nlevels;
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (p.lv[mid].cell_off <= idx) lo = mid; else hi = mid; }
     const LevelDesc d = p.lv[lo];
@@ -155,26 +244,40 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
     const int W = d.cols;
     const size_t HW = (size_t)d.rows * W;
     const int y = local / W;
-    const size_t gbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG;
-    float best = 0.0f;
-    int bi = 0;
-    if (cj.nmix == 1) {
-        best = p.dt[gbase + (size_t)cj.job_begin * HW + local] + p.biasw[cj.bias_off[0]];
-    } else {
-        best = -INFINITY;
-        for (int mm = 0; mm < cj.nmix; ++mm) {
-            const float wv = p.dt[gbase + (size_t)(cj.job_begin + mm) * HW + local] + p.biasw[cj.bias_off[mm]];
-            if (wv > best) { bi = mm; best = wv; }
+    const size_t gbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)cj.job_begin * HW;
+    float dtv[kMaxMix];
+    int ixv[kMaxMix];
+#pragma unroll
+    for (int mm = 0; mm < kMaxMix; ++mm) {
+        dtv[mm] = 0.f; ixv[mm] = 0;
+        if (mm < cj.nmix) {
+            dtv[mm] = p.dt[gbase + (size_t)mm * HW + local];
+            ixv[mm] = p.IxRaw32[gbase + (size_t)mm * HW + local];
         }
     }
-    const size_t jb = gbase + (size_t)(cj.job_begin + bi) * HW;
-    const int ix = p.IxRaw[jb + local];
-    const int iy = p.IyRaw[jb + (size_t)y * W + ix];
-    const size_t o = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + (size_t)cj.slot * HW + local;
-    p.Ix[o] = (int16_t)ix;
-    p.Iy[o] = (int16_t)iy;
-    p.Ik[o] = (uint8_t)bi;
-    p.msg[o] = best;
+    const size_t obase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + (size_t)cj.slot * HW + local;
+    for (int pm = 0; pm < cj.npar; ++pm) {
+        float best;
+        int bi = 0, ix = ixv[0];
+        if (cj.nmix == 1) {
+            best = dtv[0] + p.biasw[cj.bias_off[0] + pm];
+        } else {
+            best = -INFINITY;
+#pragma unroll
+            for (int mm = 0; mm < kMaxMix; ++mm) {
+                if (mm < cj.nmix) {
+                    const float wv = dtv[mm] + p.biasw[cj.bias_off[mm] + pm];
+                    if (wv > best) { bi = mm; best = wv; ix = ixv[mm]; }
+                }
+            }
+        }
+        const int iy = p.IyRaw[gbase + (size_t)bi * HW + (size_t)y * W + ix];
+        const size_t o = obase + (size_t)pm * HW;
+        p.Ix[o] = (int16_t)ix;
+        p.Iy[o] = (int16_t)iy;
+        p.Ik[o] = (uint8_t)bi;
+        p.msg[o] = best;
+    }
 }
 
 void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, hipStream_t s)
