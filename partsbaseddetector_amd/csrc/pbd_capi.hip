@@ -402,11 +402,16 @@ int upload_filters(pbd_handle *h, int nfilters, const float *const *filters, con
         if (ksize[f] != K) return fail(h, PBD_ERR_UNSUPPORTED, "filters of different sizes (%d vs %d) are not supported", ksize[f], K);
     if (K < 1 || K > 7) return fail(h, PBD_ERR_UNSUPPORTED, "filter size %d not supported (1..7)", K);
     const int Fpad = (nfilters + kConvQ - 1) / kConvQ * kConvQ;
-    // device layout [channel][tap][Fpad]: the 8 weights of a (channel, tap, filter group) are contiguous
+    // device layout: 5x5 kernel [group][channel][tap][8] (800 contiguous bytes per (group, channel));
+    // generic kernel [channel][tap][Fpad]
     std::vector<float> w((size_t)32 * K * K * Fpad, 0.f);
     for (int f = 0; f < nfilters; ++f)
         for (int t = 0; t < K * K; ++t)
-            for (int c = 0; c < 32; ++c) w[((size_t)c * K * K + t) * Fpad + f] = filters[f][(size_t)t * 32 + c];
+            for (int c = 0; c < 32; ++c) {
+                const float v = filters[f][(size_t)t * 32 + c];
+                if (K == 5) w[(((size_t)(f / kConvQ) * 32 + c) * K * K + t) * kConvQ + (f % kConvQ)] = v;
+                else w[((size_t)c * K * K + t) * Fpad + f] = v;
+            }
     HIPCHK(h, h->d_wts.upload(w));
     h->F = nfilters; h->Fpad = Fpad; h->ksize = K;
     h->filter_ksize.assign(ksize, ksize + nfilters);

@@ -17,21 +17,35 @@
 // Compiled with -ffp-contract=off.
 #include "pbd_internal.h"
 
+#include <algorithm>
+
 namespace pbd {
 
 // Weights are read-only for the whole launch and every address is wave-uniform: reading them
 // through the constant address space lets the compiler keep them in SGPRs (s_load_dwordx8).
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const v4f __attribute__((address_space(4))) cfloat4;
 
-template <int K, bool FMA>
-__global__ __launch_bounds__(256, 2) void k_conv(ConvParams p, const float *__restrict__ wts, const float *__restrict__ featp,
-                                                 float *__restrict__ respp)
+// K x K filters, NW waves per workgroup.  Every wave covers the whole 32 x 8 tile: lane = (x, half),
+// 4 consecutive rows per lane, whose 8 x K input window of one channel sits in registers; the waves
+// split the filter groups (wave w takes groups w, w+NW, ...).
+// Weights: the K*K*8 weights of a (group, channel) are 800 contiguous bytes in HBM ([g][c][tap][8]).
+// Each wave stages them into its own double-buffered LDS slice with one 16-byte load per lane, one
+// channel ahead of use, and reads them back with broadcast ds_read_b128 (all lanes, same address), so
+// the inner loop has no scalar-cache traffic and LDS waits can be counted (lgkmcnt(N)).
+// Per (channel, tap): 2 broadcast LDS reads and 32 multiply-adds per lane (16 packed mul + 16 packed add).
+template <int K, bool FMA, int NW>
+__global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p, const float *__restrict__ wts, const float *__restrict__ featp,
+                                                  float *__restrict__ respp)
 {
-    constexpr int TW = kConvTW, TH = kConvTH, Q = kConvQ;
+    constexpr int TW = kConvTW, TH = kConvTH, Q = kConvQ, P = 4;
     constexpr int PW = TW + K - 1, PH = TH + K - 1;
     constexpr int PLANE = (PH * PW) | 1;   // odd plane stride: conflict-free staging writes
-    __shared__ float sm[32 * PLANE];
+    constexpr int WCH = K * K * Q;         // weights of one (group, channel)
+    constexpr int WLANES = (WCH + 3) / 4;  // lanes that stage 16 bytes each
+    static_assert(WLANES <= 64, "one staging instruction per wave");
+    __shared__ __attribute__((aligned(16))) float sm[32 * PLANE + 3 + NW * 2 * WLANES * 4];
 
     const ConvTile tile = p.tiles[blockIdx.x];
     const int frame = blockIdx.z;
@@ -41,10 +55,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p, const float *__re
     const int t = threadIdx.x;
     const float *feat = featp + ((size_t)frame * p.cell_per_frame + d.cell_off) * 32;
 
-    {   // stage: lane = channel, 8 cells per pass; global reads are 128-byte cells
+    {   // stage: lane = channel, NW*2 cells per pass; global reads are 128-byte cells
         const int c = t & 31;
         const float border = (c == 31) ? 1.0f : 0.0f;
-        for (int ci = t >> 5; ci < PH * PW; ci += 8) {
+        for (int ci = t >> 5; ci < PH * PW; ci += NW * 2) {
             const int cy = ci / PW, cx = ci - cy * PW;
             const int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
             float v = border;
@@ -54,49 +68,82 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p, const float *__re
     }
     __syncthreads();
 
-    const int px = t & 31, py = t >> 5;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int px = lane & 31, py = (lane >> 5) * P;
     const int x = tile.x0 + px, y = tile.y0 + py;
-    const bool valid = (x < W) && (y < H);
     const int ngroups = p.Fpad / Q;
     const int g0 = blockIdx.y * p.groups_per_block;
     const int g1 = min(g0 + p.groups_per_block, ngroups);
     const size_t HW = (size_t)H * W;
     float *resp = respp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)y * W + x;
     const float *sp0 = sm + py * PW + px;
+    // wave-private weight slice, 16-byte aligned
+    float *wbuf = sm + ((32 * PLANE + 3) & ~3) + wave * (2 * WLANES * 4);
+    const bool wl = lane < WLANES;
 
-    for (int g = g0; g < g1; ++g) {
-        float r[Q];
+    for (int g = g0 + wave; g < g1; g += NW) {
+        const v4f *wsrc = reinterpret_cast<const v4f *>(wts + (size_t)g * 32 * WCH) + lane;
+        v4f wreg = wl ? wsrc[0] : v4f{0.f, 0.f, 0.f, 0.f};
+        if (wl) *reinterpret_cast<v4f *>(wbuf + lane * 4) = wreg;
+        v2f r[P][Q / 2];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) r[q] = 0.0f;
+        for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+            for (int q = 0; q < Q / 2; ++q) r[pp][q] = v2f{0.0f, 0.0f};
         for (int c = 0; c < 32; ++c) {
+            if (c + 1 < 32 && wl) wreg = wsrc[(size_t)(c + 1) * (WCH / 4)];   // next channel's weights, in flight during compute
             const float *sp = sp0 + c * PLANE;
-            cfloat4 *wp = (cfloat4 *)(wts + (size_t)c * (K * K) * p.Fpad + g * Q);
-            const int wstride = p.Fpad / 4;
-            float s[Q];
+            const float *wcur = wbuf + (c & 1) * (WLANES * 4);
+            // s = delta (0); s += kf[k]*src[k] over the taps in raster order (src/filter.cpp:3916-3922).
+            // Packed pairs of filters: one v_pk_mul_f32 + one v_pk_add_f32 per (pixel, filter pair), each
+            // half rounded separately exactly like the scalar sequence.  The tap-row loop is kept rolled
+            // so that only one row of weights (5 taps x 8) and one 4 x 5 input window are live at a time.
+            v2f s[P][Q / 2];
 #pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int q = 0; q < Q / 2; ++q) s[pp][q] = v2f{0.0f, 0.0f};
+#pragma clang loop unroll(disable)
             for (int i = 0; i < K; ++i) {
+                float fw[P][K];
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                    for (int j = 0; j < K; ++j) fw[pp][j] = sp[(pp + i) * PW + j];
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
-                    const float f = sp[i * PW + j];
-                    const v4f wa = wp[(size_t)(i * K + j) * wstride];
-                    const v4f wb = wp[(size_t)(i * K + j) * wstride + 1];
-                    const float w[Q] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                    const v4f wa = *reinterpret_cast<const v4f *>(wcur + (i * K + j) * Q);
+                    const v4f wb = *reinterpret_cast<const v4f *>(wcur + (i * K + j) * Q + 4);
+                    const v2f w[Q / 2] = {__builtin_shufflevector(wa, wa, 0, 1), __builtin_shufflevector(wa, wa, 2, 3),
+                                          __builtin_shufflevector(wb, wb, 0, 1), __builtin_shufflevector(wb, wb, 2, 3)};
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        if (i == 0 && j == 0) s[q] = w[q] * f;
-                        else if (FMA) s[q] = __fmaf_rn(w[q], f, s[q]);
-                        else s[q] = s[q] + w[q] * f;
+                    for (int pp = 0; pp < P; ++pp) {
+                        const v2f f = v2f{fw[pp][j], fw[pp][j]};
+#pragma unroll
+                        for (int q = 0; q < Q / 2; ++q) {
+                            if (FMA) s[pp][q] = __builtin_elementwise_fma(w[q], f, s[pp][q]);
+                            else s[pp][q] = s[pp][q] + w[q] * f;
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < Q; ++q) r[q] = r[q] + s[q];
-        }
-        if (valid) {
+            for (int pp = 0; pp < P; ++pp)
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int f = g * Q + q;
-                if (f < p.F) resp[(size_t)f * HW] = r[q];
+                for (int q = 0; q < Q / 2; ++q) r[pp][q] = r[pp][q] + s[pp][q];
+            if (c + 1 < 32 && wl) *reinterpret_cast<v4f *>(wbuf + ((c + 1) & 1) * (WLANES * 4) + lane * 4) = wreg;
+        }
+        if (x < W) {
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                if (y + pp < H) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const int f = g * Q + q;
+                        if (f < p.F) resp[(size_t)f * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
+                    }
+                }
             }
         }
     }
@@ -179,8 +226,18 @@ void launch_conv(const ConvParams &p, int nframes, hipStream_t s)
     const int gy = (ngroups + p.groups_per_block - 1) / p.groups_per_block;
     dim3 grid(p.ntiles, gy, nframes);
     if (p.ksize == 5) {
-        if (p.fma) hipLaunchKernelGGL((k_conv<5, true>), grid, dim3(256), 0, s, p, p.wts, p.feat, p.resp);
-        else hipLaunchKernelGGL((k_conv<5, false>), grid, dim3(256), 0, s, p, p.wts, p.feat, p.resp);
+        // waves per workgroup: prefer a count that divides the groups of a workgroup evenly
+        const int gb = std::min(p.groups_per_block, ngroups);
+        const int nw = (gb % 5 == 0) ? 5 : (gb % 6 == 0) ? 6 : (gb % 4 == 0) ? 4 : 5;
+#define PBD_LAUNCH_CONV(NW)                                                                                      \
+    do {                                                                                                         \
+        if (p.fma) hipLaunchKernelGGL((k_conv<5, true, NW>), grid, dim3(NW * 64), 0, s, p, p.wts, p.feat, p.resp); \
+        else hipLaunchKernelGGL((k_conv<5, false, NW>), grid, dim3(NW * 64), 0, s, p, p.wts, p.feat, p.resp);      \
+    } while (0)
+        if (nw == 5) PBD_LAUNCH_CONV(5);
+        else if (nw == 6) PBD_LAUNCH_CONV(6);
+        else PBD_LAUNCH_CONV(4);
+#undef PBD_LAUNCH_CONV
     } else {
         const int PW = kConvTW + p.ksize - 1, PH = kConvTH + p.ksize - 1;
         const size_t lds = (size_t)32 * ((PH * PW) | 1) * sizeof(float);

@@ -38,27 +38,58 @@ __device__ __forceinline__ float dt_input(const float *resp_plane, const float *
 
 // ------------------------------------------------------------------------------------------------
 // One 1-D transform per thread, streamed in chunks of CH elements.
-//   * the envelope's top entry (v[k], z[k], src[v[k]]) lives in registers; pushes are fire-and-forget
-//     stores, only pops read memory;
-//   * the stack of a wave is wave-private and lane-interleaved ([k][lane], 12-byte entries), so the hot
-//     top-of-stack lines of all resident waves fit in L2;
-//   * source values are prefetched one chunk ahead (wide per-lane loads in the rows pass, coalesced
-//     loads in the columns pass) and results leave in whole chunks.
-// The arithmetic and control flow per element are exactly computeRow's (DistanceTransform.hpp:152-182).
+//   * the envelope's top entry (v[k], z[k], src[v[k]]) lives in registers;
+//   * the T entries below it live in a per-lane LDS ring (slot = index % T, arrays [T][64] so that a
+//     lane always hits bank lane % 32: conflict-free whatever the lanes' indices are); a pop is three
+//     ds_read_b32, a push three ds_write_b32;
+//   * only when a lane's ring overflows is its oldest entry spilled to the wave-private,
+//     lane-interleaved global stack ([k][lane], 12-byte entries), and only pops below the ring read it;
+//   * the read-out walks q downwards and POPS: since z[1..ktop] is strictly increasing,
+//     "k = 0; while (z[k+1] < os) k++" (DistanceTransform.hpp:172-178, q ascending) selects the same
+//     k(q) = max{k : z[k] < os(q)} as "k = ktop; while (!(z[k] < os)) k--" with q descending;
+//   * source values are prefetched one chunk ahead and results leave in whole chunks.
+// The arithmetic per element is exactly computeRow's (DistanceTransform.hpp:152-182).
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(4))) StkEntry { float z; float s; int v; };
 
 constexpr int kDtCH = 8;
+constexpr int kDtT = 16;    // ring entries per lane
+
+struct DtRing {
+    float *z; float *s; int *v;   // this lane's column of the [T][64] arrays
+    StkEntry *g;                  // this lane's column of the global [k][lane] stack
+    int lo;                       // ring holds indices [lo, top)
+    __device__ __forceinline__ void push_below(int idx, float zk, float sk, int vk)
+    {   // entry `idx` (the old top) moves under a new top
+        const int slot = idx & (kDtT - 1);
+        if (idx - lo >= kDtT) {   // slot still holds live entry idx - T: spill it
+            g[(size_t)(idx - kDtT) * 64] = StkEntry{z[slot * 64], s[slot * 64], v[slot * 64]};
+            lo = idx - kDtT + 1;
+        }
+        z[slot * 64] = zk; s[slot * 64] = sk; v[slot * 64] = vk;
+    }
+    __device__ __forceinline__ void pop(int idx, float &zk, float &sk, int &vk)
+    {   // entry `idx` becomes the top
+        if (idx >= lo) {
+            const int slot = idx & (kDtT - 1);
+            zk = z[slot * 64]; sk = s[slot * 64]; vk = v[slot * 64];
+        } else {
+            const StkEntry e = g[(size_t)idx * 64];
+            zk = e.z; sk = e.s; vk = e.v;
+            lo = idx;
+        }
+    }
+};
 
 template <class LoadChunk, class StoreChunk>
-__device__ __forceinline__ void dt_stream(int N, double a, double b, int os, StkEntry *stk, LoadChunk load, StoreChunk store)
+__device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing ring, LoadChunk load, StoreChunk store)
 {
     constexpr int CH = kDtCH;
     float cur[CH], nxt[CH];
     load(0, cur);
     int k = 0, vk = 0;
     float zk = -INFINITY, sk = cur[0];
-    stk[0] = StkEntry{zk, sk, 0};
+    ring.lo = 0;
     for (int q0 = 0; q0 < N; q0 += CH) {
         if (q0 + CH < N) load(q0 + CH, nxt);
 #pragma unroll
@@ -69,50 +100,35 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os, Stk
                 float s = quad_isect(a, b, vk, q, sk, sq);
                 while (s <= zk && k > 0) {
                     --k;
-                    const StkEntry e = stk[(size_t)k * 64];
-                    vk = e.v; zk = e.z; sk = e.s;
+                    ring.pop(k, zk, sk, vk);
                     s = quad_isect(a, b, vk, q, sk, sq);
                 }
+                ring.push_below(k, zk, sk, vk);
                 ++k;
                 vk = q; zk = s; sk = sq;
-                stk[(size_t)k * 64] = StkEntry{zk, sk, vk};
             }
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
     }
-    const int ktop = k;
-    k = 0;
-    {
-        const StkEntry e = stk[0];
-        vk = e.v; sk = e.s;
-    }
-    float znext = INFINITY, snext = 0.f;
-    int vnext = 0;
-    if (ktop >= 1) {
-        const StkEntry e = stk[64];
-        znext = e.z; snext = e.s; vnext = e.v;
-    }
-    for (int q0 = 0; q0 < N; q0 += CH) {
+    // read-out, q descending
+    const int nch = (N + CH - 1) / CH;
+    for (int cidx = nch - 1; cidx >= 0; --cidx) {
+        const int q0 = cidx * CH;
         float out[CH];
         int ptr[CH];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
+        for (int i = CH - 1; i >= 0; --i) {
             out[i] = 0.f; ptr[i] = 0;
-            if (q0 + i < N) {
-                while (znext < (float)os) {
-                    ++k;
-                    vk = vnext; sk = snext;
-                    if (k + 1 <= ktop) {
-                        const StkEntry e = stk[(size_t)(k + 1) * 64];
-                        znext = e.z; snext = e.s; vnext = e.v;
-                    } else {
-                        znext = INFINITY;
-                    }
+            const int q = q0 + i;
+            if (q < N) {
+                const float osf = (float)(os0 + q);
+                while (!(zk < osf)) {   // z[0] = -inf ends the walk
+                    --k;
+                    ring.pop(k, zk, sk, vk);
                 }
-                out[i] = quad_val(a, b, os - vk, sk);
+                out[i] = quad_val(a, b, os0 + q - vk, sk);
                 ptr[i] = vk;
-                ++os;
             }
         }
         store(q0, out, ptr);
@@ -140,8 +156,11 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
     const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y * W;
     float *tmp = p.tmp + obase;
     int *ixr = p.IxRaw32 + obase;
-    StkEntry *stk = reinterpret_cast<StkEntry *>(p.stk) +
-                    ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[blockIdx.x]) + threadIdx.x;
+    __shared__ float ring_z[kDtT * 64], ring_s[kDtT * 64];
+    __shared__ int ring_v[kDtT * 64];
+    DtRing ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
+                reinterpret_cast<StkEntry *>(p.stk) +
+                    ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[blockIdx.x]) + threadIdx.x, 0};
     const int *cs = p.child_slots;
     const int cb = job.child_begin, ce = job.child_end;
     const int N = active ? W : 0;
@@ -180,7 +199,7 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
                 if (q0 + i < N) { tmp[q0 + i] = out[i]; ixr[q0 + i] = ptr[i]; }
         }
     };
-    dt_stream(N, job.ax, job.bx, job.osx, stk, load, store);
+    dt_stream(N, job.ax, job.bx, job.osx, ring, load, store);
 }
 
 void launch_dt_rows(const DpParams &p, int nframes, hipStream_t s)
@@ -206,8 +225,11 @@ __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
     const float *tmp = p.tmp + base;
     float *dt = p.dt + base;
     int16_t *iyr = p.IyRaw + base;
-    StkEntry *stk = reinterpret_cast<StkEntry *>(p.stk) +
-                    ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[blockIdx.x]) + threadIdx.x;
+    __shared__ float ring_z[kDtT * 64], ring_s[kDtT * 64];
+    __shared__ int ring_v[kDtT * 64];
+    DtRing ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
+                reinterpret_cast<StkEntry *>(p.stk) +
+                    ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[blockIdx.x]) + threadIdx.x, 0};
     auto load = [&](int q0, float *buf) {
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmp[(size_t)(q0 + i) * W] : 0.f;
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
         for (int i = 0; i < kDtCH; ++i)
             if (q0 + i < H) { dt[(size_t)(q0 + i) * W] = out[i]; iyr[(size_t)(q0 + i) * W] = (int16_t)ptr[i]; }
     };
-    dt_stream(H, job.ay, job.by, job.osy, stk, load, store);
+    dt_stream(H, job.ay, job.by, job.osy, ring, load, store);
 }
 
 void launch_dt_cols(const DpParams &p, int nframes, hipStream_t s)
