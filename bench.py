@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--conv-mode", choices=["exact", "fma"], default="exact")
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same workload timed on the host CPU")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the same workload timed on the host CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     return ap.parse_args()
@@ -78,23 +78,16 @@ def main():
     d_frames = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
 
-    # gather payload: [count | cap_g records]; latency-bound (KBs-MBs), one collective per step
+    # gather payload: [count | cap_g records] per rank; latency-bound (KBs-MBs), ONE collective per step
+    from partsbaseddetector_amd import dist as pdist
     cap_g = 8192
-    send = torch.zeros(1 + cap_g * stride, dtype=torch.int32, device="cuda")
-    recv = [torch.zeros_like(send) for _ in range(world)] if world > 1 else None
+    dev = torch.device("cuda", local_rank)
 
     def step():
         buf, n = det.detect_batch_device(d_frames.data_ptr(), B, rows, cols, cn, raw=True)
         if world > 1:
-            m = min(n, cap_g)
-            host = np.empty(1 + cap_g * stride, np.int32)
-            host[0] = m
-            host[1:1 + m * stride] = buf[:m * stride]
-            send.copy_(torch.from_numpy(host), non_blocking=False)
-            dist.all_gather(recv, send)
-            if rank == 0:
-                tot = int(sum(int(r[0].item()) for r in recv))
-                return tot
+            rec = pdist.gather_candidates(buf, n, stride, cap_g, frame_offset=rank * B, device=dev)
+            return len(rec)
         return n
 
     def sync():
@@ -138,6 +131,9 @@ def main():
                     stage_ms[k] = round(ms / args.steps, 4)
             ms, n = prof["k_conv"]
             if n:
+                # launches per step may exceed 1 (chunked pipeline): scale the per-batch work to one launch
+                per_step = n / args.steps
+                conv_flop, conv_bytes = conv_flop / per_step, int(conv_bytes / per_step)
                 avg_s = ms / n * 1e-3
                 tfl = conv_flop / avg_s / 1e12
                 traffic = None
@@ -156,8 +152,11 @@ def main():
                                     "peak (vector = f32-MFMA rate); exact mode issues mul and add separately"}
         cpu = None
         if not args.no_cpu_baseline:
+            # the GPU box's CPU share for one GPU is 16 cores; use at most that many OpenMP threads
+            ncpu = min(len(os.sched_getaffinity(0)), 16)
             from oracle import oracle   # CPU restatement: the reported baseline, never the measured path
             oracle.build()
+            oracle.set_num_threads(ncpu)
             nf = max(1, args.cpu_frames)
             oracle.detect(flat, frames[0])            # warm-up (page-in, thread pool)
             t1 = time.perf_counter()

@@ -78,6 +78,10 @@ def num_threads() -> int:
     return lib().pbdo_num_threads()
 
 
+def set_num_threads(n: int) -> None:
+    lib().pbdo_set_num_threads(int(n))
+
+
 def pyramid_plan(rows, cols, sbin, interval):
     lr = np.zeros(MAX_LEVELS, np.int32)
     lc = np.zeros(MAX_LEVELS, np.int32)

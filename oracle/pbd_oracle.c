@@ -26,6 +26,15 @@ static double now_ms(void)
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+void pbdo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int pbdo_num_threads(void)
 {
 #ifdef _OPENMP

@@ -138,6 +138,7 @@ int pbdo_features_f32(const pbdo_model *m, const uint8_t *im, int rows, int cols
 void pbdo_responses_f32(const pbdo_model *m, const float *feat, int H, int W, float *resp /*nfilters*H*W*/);
 
 int pbdo_num_threads(void);
+void pbdo_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -163,7 +164,9 @@ struct Prof {
 struct pbd_handle {
     pbd_config cfg{};
     std::string err;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // pyramid, HOG, convolution (and everything in the staged calls)
+    hipStream_t stream2 = nullptr;     // dynamic program of the previous chunk, overlapped with the convolution
+    std::vector<hipEvent_t> chunk_events;
     bool own_stream = false;
 
     // model (host copies)
@@ -223,14 +226,14 @@ int fail(pbd_handle *h, int code, const char *fmt, ...)
     } while (0)
 
 struct ProfScope {
-    pbd_handle *h; int k; hipEvent_t a{}, b{};
-    ProfScope(pbd_handle *h_, int k_) : h(h_), k(k_)
+    pbd_handle *h; int k; hipStream_t st; hipEvent_t a{}, b{};
+    ProfScope(pbd_handle *h_, int k_, hipStream_t st_) : h(h_), k(k_), st(st_)
     {
-        if (h->prof.on) { a = h->prof.get(); b = h->prof.get(); (void)hipEventRecord(a, h->stream); }
+        if (h->prof.on) { a = h->prof.get(); b = h->prof.get(); (void)hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
-        if (h->prof.on) { (void)hipEventRecord(b, h->stream); h->prof.recs.push_back({k, a, b}); }
+        if (h->prof.on) { (void)hipEventRecord(b, st); h->prof.recs.push_back({k, a, b}); }
     }
 };
 
@@ -573,70 +576,85 @@ int build_model(pbd_handle *h, const pbd_model *m)
 }
 
 // ---- stages --------------------------------------------------------------------------------------
-int run_features(pbd_handle *h, Plan &P, int nframes)
+// alloc_* size the grow-only workspace for `nframes`; launch_* enqueue the kernels for frames
+// [f0, f0+nb) on stream `st` (no allocation, no synchronisation inside).
+int alloc_features(pbd_handle *h, Plan &P, int nframes)
 {
-    const int cn = P.cn;
-    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * cn));
+    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * P.cn));
     HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * sizeof(float)));
     HIPCHK(h, h->norm.ensure((size_t)nframes * P.blk_per_frame * sizeof(float)));
     HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * 32 * sizeof(float), 16)));
+    return PBD_OK;
+}
+
+void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int f0, int nb, hipStream_t st)
+{
+    const int cn = P.cn;
     PyrParams pp{};
-    pp.lv = P.d_lv.d; pp.nlevels = P.nlevels; pp.interval = std::min(P.interval, P.nlevels); pp.cn = cn;
-    pp.pix_per_frame = P.pix_per_frame; pp.pyr = h->pyr.as<uint8_t>(); pp.frames = h->frames.as<uint8_t>();
+    pp.lv = P.d_lv.d; pp.nlevels = P.nlevels; pp.interval = std::min(P.interval, P.nlevels); pp.cn = cn; pp.frame0 = f0;
+    pp.pix_per_frame = P.pix_per_frame; pp.pyr = h->pyr.as<uint8_t>(); pp.frames = static_cast<const uint8_t *>(d_frames);
     pp.rows = P.rows; pp.cols = P.cols; pp.tabx = P.d_tabx.d; pp.taby = P.d_taby.d;
     {
-        ProfScope ps(h, PBD_K_RESIZE);
-        launch_resize(pp, nframes, P.npix_resized, h->stream);
+        ProfScope ps(h, PBD_K_RESIZE, st);
+        launch_resize(pp, nb, P.npix_resized, st);
     }
     for (int first = P.interval; first < P.nlevels; first += P.interval) {
         const int last = std::min(first + P.interval, P.nlevels);
         const long long base = P.lv[first].img_off;
         const long long end = (last < P.nlevels) ? P.lv[last].img_off : P.pix_per_frame;
-        ProfScope ps(h, PBD_K_PYRDOWN);
-        launch_pyrdown_range(pp, nframes, first, last, base, end - base, h->stream);
+        ProfScope ps(h, PBD_K_PYRDOWN, st);
+        launch_pyrdown_range(pp, nb, first, last, base, end - base, st);
     }
     HogParams hp{};
-    hp.lv = P.d_lv.d; hp.nlevels = P.nlevels; hp.cn = cn; hp.sbin = h->sbin;
+    hp.lv = P.d_lv.d; hp.nlevels = P.nlevels; hp.cn = cn; hp.sbin = h->sbin; hp.frame0 = f0;
     hp.pix_per_frame = P.pix_per_frame; hp.blk_per_frame = P.blk_per_frame; hp.cell_per_frame = P.cell_per_frame;
     hp.pyr = h->pyr.as<uint8_t>(); hp.coord = h->d_coord.d;
     hp.hist = h->hist.as<float>(); hp.norm = h->norm.as<float>(); hp.feat = h->feat.as<float>();
     {
-        ProfScope ps(h, PBD_K_HOG_HIST);
-        launch_hog_hist(hp, nframes, h->stream);
+        ProfScope ps(h, PBD_K_HOG_HIST, st);
+        launch_hog_hist(hp, nb, st);
     }
     {
-        ProfScope ps(h, PBD_K_HOG_FEAT);
-        launch_hog_feat(hp, nframes, h->stream);
+        ProfScope ps(h, PBD_K_HOG_FEAT, st);
+        launch_hog_feat(hp, nb, st);
     }
-    HIPCHK(h, hipGetLastError());
-    h->have_features = true;
-    return PBD_OK;
 }
 
-int run_conv(pbd_handle *h, Plan &P, int nframes)
+int alloc_conv(pbd_handle *h, Plan &P, int nframes)
 {
     if (!h->filters_set) return fail(h, PBD_ERR_STATE, "pdf() before setFilters()");
     HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * h->F * sizeof(float), 16)));
-    ConvParams cp{};
-    cp.lv = P.d_lv.d; cp.tiles = P.d_tiles.d; cp.ntiles = P.ntiles;
-    cp.F = h->F; cp.Fpad = h->Fpad; cp.ksize = h->ksize;
-    const int ngroups = h->Fpad / kConvQ;
-    // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
-    const long long wgs = (long long)P.ntiles * nframes;
-    cp.groups_per_block = wgs >= 2048 ? ngroups : std::max(1, (int)(ngroups * wgs / 2048));
-    cp.cell_per_frame = P.cell_per_frame;
-    cp.feat = h->feat.as<float>(); cp.wts = h->d_wts.d; cp.resp = h->resp.as<float>();
-    cp.fma = h->cfg.conv_mode == PBD_CONV_FMA;
-    {
-        ProfScope ps(h, PBD_K_CONV);
-        launch_conv(cp, nframes, h->stream);
-    }
-    HIPCHK(h, hipGetLastError());
-    h->have_resp = true;
     return PBD_OK;
 }
 
-int run_dp(pbd_handle *h, Plan &P, int nframes)
+void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
+{
+    ConvParams cp{};
+    cp.lv = P.d_lv.d; cp.tiles = P.d_tiles.d; cp.ntiles = P.ntiles;
+    cp.F = h->F; cp.Fpad = h->Fpad; cp.ksize = h->ksize; cp.frame0 = f0;
+    const int ngroups = h->Fpad / kConvQ;
+    // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
+    const long long wgs = (long long)P.ntiles * nb;
+    cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
+    cp.cell_per_frame = P.cell_per_frame;
+    cp.feat = h->feat.as<float>(); cp.wts = h->d_wts.d; cp.resp = h->resp.as<float>();
+    cp.fma = h->cfg.conv_mode == PBD_CONV_FMA;
+    ProfScope ps(h, PBD_K_CONV, st);
+    launch_conv(cp, nb, st);
+}
+
+// frames per DP chunk so that the chunk scratch stays within the budget
+int dp_chunk_frames(pbd_handle *h, Plan &P, int want)
+{
+    const size_t per_frame = (size_t)P.cell_per_frame * std::max(h->JGmax, 1);
+    const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
+    const size_t budget = (size_t)8 << 30;   // bytes of scratch per chunk (14 B / cell-job + 12 B / stack entry)
+    int chunk = std::max(want, 1);
+    while (chunk > 1 && (per_frame * 14 + stk_per_frame * 12) * chunk > budget) chunk = (chunk + 1) / 2;
+    return chunk;
+}
+
+int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
 {
     const size_t cpf = (size_t)P.cell_per_frame;
     const int NSa = std::max(h->NS, 1);
@@ -646,18 +664,19 @@ int run_dp(pbd_handle *h, Plan &P, int nframes)
     HIPCHK(h, h->Ik.ensure(std::max<size_t>((size_t)nframes * cpf * NSa, 16)));
     HIPCHK(h, h->rootv.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(float), 16)));
     HIPCHK(h, h->rooti.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(int), 16)));
-    // scratch for one chunk of frames: bounded so that a batch does not multiply the DT intermediates
     const size_t per_frame = cpf * std::max(h->JGmax, 1);
-    int chunk = nframes;
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
-    const size_t budget = (size_t)8 << 30;   // bytes of scratch per chunk (14 B / cell-job + 12 B / stack entry)
-    while (chunk > 1 && (per_frame * 14 + stk_per_frame * 12) * chunk > budget) chunk = (chunk + 1) / 2;
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
     HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
     HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int), 16)));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * 12, 16)));
+    return PBD_OK;
+}
 
+// dynamic program for frames [f0, f0+nb), nb <= the chunk size given to alloc_dp
+void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
+{
     DpParams dp{};
     dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC;
     dp.cell_per_frame = P.cell_per_frame;
@@ -671,19 +690,44 @@ int run_dp(pbd_handle *h, Plan &P, int nframes)
     dp.row2level = P.d_row2level.d; dp.rowoff = P.d_rowoff.d; dp.col2level = P.d_col2level.d; dp.coloff = P.d_coloff.d;
     dp.nrows_flat = P.nrows_flat; dp.ncols_flat = P.ncols_flat;
     dp.rootv = h->rootv.as<float>(); dp.rooti = h->rooti.as<int>(); dp.rjobs = h->d_rjobs.d;
-
-    for (int f0 = 0; f0 < nframes; f0 += chunk) {
-        const int nb = std::min(chunk, nframes - f0);
-        dp.frame0 = f0;
-        for (auto &g : h->groups) {
-            dp.JG = (int)g.jobs.size();
-            dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d;
-            { ProfScope ps(h, PBD_K_DT_ROWS); launch_dt_rows(dp, nb, h->stream); }
-            { ProfScope ps(h, PBD_K_DT_COLS); launch_dt_cols(dp, nb, h->stream); }
-            { ProfScope ps(h, PBD_K_DP_COMBINE); launch_dp_combine(dp, (int)g.cjobs.size(), nb, h->stream); }
-        }
-        { ProfScope ps(h, PBD_K_DP_ROOT); launch_dp_root(dp, nb, h->stream); }
+    dp.frame0 = f0;
+    for (auto &g : h->groups) {
+        dp.JG = (int)g.jobs.size();
+        dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d;
+        { ProfScope ps(h, PBD_K_DT_ROWS, st); launch_dt_rows(dp, nb, st); }
+        { ProfScope ps(h, PBD_K_DT_COLS, st); launch_dt_cols(dp, nb, st); }
+        { ProfScope ps(h, PBD_K_DP_COMBINE, st); launch_dp_combine(dp, (int)g.cjobs.size(), nb, st); }
     }
+    { ProfScope ps(h, PBD_K_DP_ROOT, st); launch_dp_root(dp, nb, st); }
+}
+
+// single-stream wrappers used by the staged entry points
+int run_features(pbd_handle *h, Plan &P, int nframes)
+{
+    int rc = alloc_features(h, P, nframes);
+    if (rc != PBD_OK) return rc;
+    launch_features(h, P, h->frames.p, 0, nframes, h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->have_features = true;
+    return PBD_OK;
+}
+
+int run_conv(pbd_handle *h, Plan &P, int nframes)
+{
+    int rc = alloc_conv(h, P, nframes);
+    if (rc != PBD_OK) return rc;
+    launch_conv_stage(h, P, 0, nframes, h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->have_resp = true;
+    return PBD_OK;
+}
+
+int run_dp(pbd_handle *h, Plan &P, int nframes)
+{
+    const int chunk = dp_chunk_frames(h, P, nframes);
+    int rc = alloc_dp(h, P, nframes, chunk);
+    if (rc != PBD_OK) return rc;
+    for (int f0 = 0; f0 < nframes; f0 += chunk) launch_dp_chunk(h, P, f0, std::min(chunk, nframes - f0), h->stream);
     HIPCHK(h, hipGetLastError());
     h->have_dp = true;
     return PBD_OK;
@@ -707,7 +751,7 @@ int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32
     ap.count = h->count.as<int>(); ap.cand = h->cand.as<int32_t>();
     int found = 0;
     {
-        ProfScope ps(h, PBD_K_ARGMIN);
+        ProfScope ps(h, PBD_K_ARGMIN, h->stream);
         launch_argmin_find(ap, h->stream);
     }
     HIPCHK(h, hipMemcpyAsync(&found, h->count.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -716,7 +760,7 @@ int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32
     const int n = std::min(found, cap);
     if (n > 0) {
         {
-            ProfScope ps(h, PBD_K_ARGMIN);
+            ProfScope ps(h, PBD_K_ARGMIN, h->stream);
             launch_argmin_walk(ap, n, h->stream);
         }
         h->cand_host.resize((size_t)n * stride);
@@ -758,14 +802,46 @@ int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, in
     if (rc != PBD_OK) return rc;
     h->cur = P; h->cur_frames = nframes;
     h->have_features = h->have_resp = h->have_dp = false;
-    // the kernels read frames through h->frames; alias the caller's device buffer without copying
-    DevBuf saved = h->frames;
-    h->frames.p = const_cast<void *>(d_frames);
-    rc = run_features(h, *P, nframes);
-    h->frames = saved;
-    if (rc != PBD_OK) return rc;
-    if ((rc = run_conv(h, *P, nframes)) != PBD_OK) return rc;
-    if ((rc = run_dp(h, *P, nframes)) != PBD_OK) return rc;
+    // Software pipeline over chunks of frames: features + convolution of chunk c run on `stream`, the
+    // dynamic program of chunk c-1 on `stream2`.  The convolution is VALU-bound and the distance
+    // transform latency-bound, so the two overlap well; buffers are indexed by frame, so chunks never
+    // alias, and the DP scratch belongs to stream2 alone.
+    // (measured on MI355X: with the convolution holding 127 KB of LDS per CU the DP kernels get too few
+    //  waves to profit, so the pipeline is off unless PBD_PIPELINE_CHUNKS asks for it)
+    static const int env_chunks = getenv("PBD_PIPELINE_CHUNKS") ? atoi(getenv("PBD_PIPELINE_CHUNKS")) : 1;
+    const int want = env_chunks > 1 ? (nframes + env_chunks - 1) / env_chunks : nframes;
+    const int chunk = dp_chunk_frames(h, *P, want);
+    if ((rc = alloc_features(h, *P, nframes)) != PBD_OK) return rc;
+    if ((rc = alloc_conv(h, *P, nframes)) != PBD_OK) return rc;
+    if ((rc = alloc_dp(h, *P, nframes, chunk)) != PBD_OK) return rc;
+    const int nchunks = (nframes + chunk - 1) / chunk;
+    while ((int)h->chunk_events.size() < nchunks + 1) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->chunk_events.push_back(e);
+    }
+    const bool two = nchunks > 1 && h->stream2 != nullptr;
+    hipStream_t sdp = two ? h->stream2 : h->stream;
+    if (two) {   // stream2 must not start before earlier work on `stream` (frame upload, previous call)
+        HIPCHK(h, hipEventRecord(h->chunk_events[nchunks], h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->chunk_events[nchunks], 0));
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        const int f0 = c * chunk, nb = std::min(chunk, nframes - f0);
+        launch_features(h, *P, d_frames, f0, nb, h->stream);
+        launch_conv_stage(h, *P, f0, nb, h->stream);
+        if (two) {
+            HIPCHK(h, hipEventRecord(h->chunk_events[c], h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->stream2, h->chunk_events[c], 0));
+        }
+        launch_dp_chunk(h, *P, f0, nb, sdp);
+    }
+    if (two) {   // join: argmin runs on `stream` after the last DP chunk
+        HIPCHK(h, hipEventRecord(h->chunk_events[nchunks], h->stream2));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->chunk_events[nchunks], 0));
+    }
+    HIPCHK(h, hipGetLastError());
+    h->have_features = h->have_resp = h->have_dp = true;
     return run_argmin(h, *P, nframes, P->d_scales.d, cand, capacity, ncand);
 }
 
@@ -786,6 +862,9 @@ int upload_frames(pbd_handle *h, int nframes, const void *const *imgs, int rows,
 extern "C" {
 
 const char *pbd_version(void) { return "pbd-hip 0.1 (gfx950)"; }
+
+// diagnostics, not part of include/pbd.h
+int pbd_debug_conv_occupancy(int nw) { return conv_occupancy(nw); }
 
 const char *pbd_last_error(const pbd_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -814,6 +893,8 @@ int pbd_create(const pbd_model *model, const pbd_config *config, pbd_handle **ou
         if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
         h->own_stream = true;
     }
+    e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     int rc = build_model(h.get(), model);
     if (rc != PBD_OK) {
         g_create_error = h->err;
@@ -829,7 +910,10 @@ void pbd_destroy(pbd_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     h->prof.release();
+    for (auto e : h->chunk_events) (void)hipEventDestroy(e);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (DevBuf *b : {&h->frames, &h->pyr, &h->hist, &h->norm, &h->feat, &h->resp, &h->msg, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
                       &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
@@ -1090,6 +1174,7 @@ int pbd_synchronize(pbd_handle *h)
 {
     if (!h) return PBD_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
     return PBD_OK;
 }
 

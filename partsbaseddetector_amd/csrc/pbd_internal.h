@@ -71,6 +71,7 @@ constexpr int kConvTW = 32, kConvTH = 8, kConvQ = 8;
 struct PyrParams {
     const LevelDesc *lv;
     int nlevels, interval, cn;
+    int frame0;                   // first frame of this launch (grid index 0)
     long long pix_per_frame;      // pixels (not bytes) of all level images of one frame
     uint8_t *pyr;                 // [frames][pix_per_frame*cn]
     const uint8_t *frames;        // [frames][rows*cols*cn] dense
@@ -82,6 +83,7 @@ struct PyrParams {
 struct HogParams {
     const LevelDesc *lv;
     int nlevels, cn, sbin;
+    int frame0;
     long long pix_per_frame, blk_per_frame, cell_per_frame;
     const uint8_t *pyr;
     const HogCoord *coord;
@@ -96,6 +98,7 @@ struct ConvParams {
     int ntiles;
     int F, Fpad, ksize;
     int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
+    int frame0;
     long long cell_per_frame;
     const float *feat;            // [frames][cell_per_frame*32]
     const float *wts;             // [32][k*k][Fpad]
@@ -154,6 +157,7 @@ void launch_pyrdown_range(const PyrParams &p, int nframes, int first_level, int 
 void launch_hog_hist(const HogParams &p, int nframes, hipStream_t s);
 void launch_hog_feat(const HogParams &p, int nframes, hipStream_t s);
 void launch_conv(const ConvParams &p, int nframes, hipStream_t s);
+int conv_occupancy(int nw);
 void launch_dt_rows(const DpParams &p, int nframes, hipStream_t s);
 void launch_dt_cols(const DpParams &p, int nframes, hipStream_t s);
 void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, hipStream_t s);

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p
     __shared__ __attribute__((aligned(16))) float sm[32 * PLANE + 3 + NW * 2 * WLANES * 4];
 
     const ConvTile tile = p.tiles[blockIdx.x];
-    const int frame = blockIdx.z;
+    const int frame = p.frame0 + blockIdx.z;
     const LevelDesc d = p.lv[tile.level];
     const int H = d.rows, W = d.cols;
     constexpr int a = K / 2;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
     const int PW = TW + K - 1, PH = TH + K - 1;
     const int PLANE = (PH * PW) | 1;
     const ConvTile tile = p.tiles[blockIdx.x];
-    const int frame = blockIdx.z;
+    const int frame = p.frame0 + blockIdx.z;
     const LevelDesc d = p.lv[tile.level];
     const int H = d.rows, W = d.cols;
     const int a = K / 2;
@@ -217,6 +217,15 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
             }
         }
     }
+}
+
+int conv_occupancy(int nw)
+{   // resident workgroups per CU of the exact 5x5 kernel (diagnostics)
+    int n = -1;
+    if (nw == 5) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv<5, false, 5>, 320, 0);
+    if (nw == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv<5, false, 4>, 256, 0);
+    if (nw == 6) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv<5, false, 6>, 384, 0);
+    return n;
 }
 
 void launch_conv(const ConvParams &p, int nframes, hipStream_t s)

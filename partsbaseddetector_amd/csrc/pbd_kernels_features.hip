@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_resize(PyrParams p, long long npix)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix) return;
-    const int frame = blockIdx.y;
+    const int frame = p.frame0 + blockIdx.y;
     const int l = find_level<0>(p.lv, 0, p.interval, idx);
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.img_off);
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_pyrdown(PyrParams p, int first_level, i
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix) return;
-    const int frame = blockIdx.y;
+    const int frame = p.frame0 + blockIdx.y;
     const int l = find_level<0>(p.lv, first_level, last_level, idx + base);
     const LevelDesc d = p.lv[l];
     const LevelDesc sd = p.lv[d.src_level];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.blk_per_frame) return;
-    const int frame = blockIdx.y;
+    const int frame = p.frame0 + blockIdx.y;
     const int l = find_level<1>(p.lv, 0, p.nlevels, idx);
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.blk_off);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_hog_feat(HogParams p)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.cell_per_frame) return;
-    const int frame = blockIdx.y;
+    const int frame = p.frame0 + blockIdx.y;
     const int l = find_level<2>(p.lv, 0, p.nlevels, idx);
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.cell_off);

@@ -1,0 +1,86 @@
+"""world_size-2 gloo rehearsal of the multi-GPU path: frames sharded in contiguous blocks, ONE
+all_gather of fixed-capacity candidate payloads, concatenation in rank (= frame) order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from partsbaseddetector_amd import dist as pd
+
+
+def test_shard_range_covers_all_frames():
+    for n in (1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            got = [pd.shard_range(n, r, world) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n
+            for a, b in zip(got, got[1:]):
+                assert a[1] == b[0]
+            sizes = [e - b for b, e in got]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip_and_truncation():
+    stride = 8 + 4 * 3
+    rng = np.random.default_rng(0)
+    buf = rng.integers(0, 1000, 5 * stride).astype(np.int32)
+    p = pd.pack_candidates(buf, 5, stride, cap=8, frame_offset=10)
+    assert p.size == 1 + 8 * stride and p[0] == 5
+    rec = pd.unpack_gathered([p], stride)
+    assert rec.shape == (5, stride)
+    assert np.array_equal(rec[:, 1:], buf.reshape(5, stride)[:, 1:])
+    assert np.array_equal(rec[:, 0], buf.reshape(5, stride)[:, 0] + 10)
+    assert pd.pack_candidates(buf, 5, stride, cap=3)[0] == 3       # capacity clamps
+    assert pd.unpack_gathered([pd.pack_candidates(buf, 0, stride, cap=4)], stride).shape == (0, stride)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nframes, stride, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = pd.shard_range(nframes, rank, world)
+    # fake per-rank detections: frame-local ids 0.., 1 + (global frame % 3) records per frame
+    recs = []
+    for f in range(b, e):
+        for j in range(1 + f % 3):
+            r = np.zeros(stride, np.int32)
+            r[0] = f - b            # local frame index, as pbd_detect_batch returns it
+            r[1:] = 1000 * f + j
+            recs.append(r)
+    buf = np.concatenate(recs) if recs else np.zeros(0, np.int32)
+    got = pd.gather_candidates(buf, len(recs), stride, cap=64, frame_offset=b, device="cpu")
+    dist.barrier()
+    if rank == 0:
+        out.put(got)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nframes", [(2, 7), (2, 1)])
+def test_gather_candidates_world2(world, nframes):
+    stride = 8 + 4 * 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, stride, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = []
+    for f in range(nframes):
+        for j in range(1 + f % 3):
+            want.append([f] + [1000 * f + j] * (stride - 1))
+    assert np.array_equal(got, np.asarray(want, np.int32).reshape(-1, stride))
