@@ -8,6 +8,8 @@
  *
  * Layouts at the seam are the reference's:
  *   image    rows x cols x channels, uint8, interleaved BGR (channels 3) or grey (channels 1)
+ * T below is the handle's real type: float for PBD_REAL_F32 (src/demo.cpp:85), double for PBD_REAL_F64
+ * (cells/detect.cpp:93, ros/Node.hpp:121); real-typed buffers cross the ABI as void pointers to T.
  *   feature  Mat(H, W*flen) single-channel T, channel fastest        (src/HOGFeatures.cpp:180,288)
  *   filter   Mat(k, k*flen) T, same interleave                       (src/MatlabIOModel.cpp:115-123)
  *   response Mat(H, W) T, one per (level, filter): responses[level][filter]
@@ -72,7 +74,7 @@ enum { PBD_CONV_EXACT = 0,   /* multiply and add rounded separately in the refer
 
 typedef struct pbd_config {
     int device;            /* HIP device ordinal */
-    int real_type;         /* PBD_REAL_F32 (src/demo.cpp:85); PBD_REAL_F64 not yet built -> PBD_ERR_UNSUPPORTED */
+    int real_type;         /* PBD_REAL_F32 (src/demo.cpp:85) or PBD_REAL_F64 (cells/detect.cpp:93) */
     int conv_mode;         /* PBD_CONV_EXACT / PBD_CONV_FMA */
     int max_batch;         /* frames per pbd_detect_batch* call (>= 1) */
     int max_candidates;    /* candidate capacity per batch */
@@ -109,21 +111,21 @@ int pbd_binsize(const pbd_handle *h);                      /* IFeatures::binsize
  * IFeatures::nscales()/scales().  Arrays hold PBD_MAX_LEVELS entries. */
 int pbd_pyramid_plan(pbd_handle *h, int rows, int cols, int *nlevels, int *img_rows, int *img_cols,
                      int *feat_rows, int *feat_cols, float *scales);
-/* IFeatures::pyramid(im, pyrafeatures): feat[l] receives feat_rows[l] x (feat_cols[l]*flen) floats.
+/* IFeatures::pyramid(im, pyrafeatures): feat[l] receives feat_rows[l] x (feat_cols[l]*flen) values of T.
  * stride_bytes: byte distance between image rows (cv::Mat::step). depth_code: 0 = 8-bit unsigned. */
 int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int channels,
-                         size_t stride_bytes, int depth_code, float *const *feat);
+                         size_t stride_bytes, int depth_code, void *const *feat);
 /* the resampled level images of the last pbd_features_pyramid / pbd_detect call (for tests) */
 int pbd_get_pyramid_image(pbd_handle *h, int frame, int level, uint8_t *dst);
 
 /* ---- IConvolutionEngine (include/IConvolutionEngine.hpp:44-68), SpatialConvolutionEngine. */
-/* setFilters(filters): filters[f] is ksize[f] x (ksize[f]*flen) floats.  pbd_create already
+/* setFilters(filters): filters[f] is ksize[f] x (ksize[f]*flen) values of T.  pbd_create already
  * installs the model's filters; this replaces them (src/SpatialConvolutionEngine.cpp:133-159). */
-int pbd_conv_set_filters(pbd_handle *h, int nfilters, const float *const *filters, const int *ksize);
+int pbd_conv_set_filters(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize);
 /* pdf(features, responses): resp[l] receives nfilters planes of rows[l] x cols[l]
  * (responses[l][f] at resp[l] + f*rows[l]*cols[l]) (src/SpatialConvolutionEngine.cpp:106-124). */
-int pbd_conv_pdf(pbd_handle *h, int nlevels, const float *const *feat, const int *rows, const int *cols,
-                 float *const *resp);
+int pbd_conv_pdf(pbd_handle *h, int nlevels, const void *const *feat, const int *rows, const int *cols,
+                 void *const *resp);
 
 /* ---- DynamicProgram<T> (include/DynamicProgram.hpp:74-75). */
 int pbd_num_ptr_slots(const pbd_handle *h);   /* back-pointer maps per (level): sum over non-root parts of parent mixtures */
@@ -131,8 +133,8 @@ int pbd_ptr_slot(const pbd_handle *h, int component, int part); /* slot of (part
 /* min(parts, scores, Ix, Iy, Ik, rootv, rooti) (src/DynamicProgram.cpp:67-173).
  * resp[l]: nfilters planes; Ix/Iy/Ik[l]: pbd_num_ptr_slots planes of int32 (plane slot(part)+m =
  * reference Ix[l][c][part][m]); rootv[l]/rooti[l]: ncomponents planes. */
-int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, const float *const *resp,
-               int32_t *const *Ix, int32_t *const *Iy, int32_t *const *Ik, float *const *rootv,
+int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, const void *const *resp,
+               int32_t *const *Ix, int32_t *const *Iy, int32_t *const *Ik, void *const *rootv,
                int32_t *const *rooti);
 /* argmin(parts, rootv, rooti, scales, Ix, Iy, Ik, candidates) (src/DynamicProgram.cpp:190-255) on
  * the device-resident result of the last pbd_dp_min / pbd_detect*.  Candidates are written sorted by

@@ -184,12 +184,15 @@ struct pbd_handle {
     bool filters_set = false;
 
     // device model tables
-    DevTable<float> d_wts, d_biasw;
+    DevBuf d_wts;                    // real-typed weights
+    DevTable<float> d_biasw;
     DevTable<int> d_child_slots, d_walk_off;
     DevTable<RootJob> d_rjobs;
     DevTable<PartWalk> d_walk;
-    DevTable<HogCoord> d_coord;
+    DevBuf d_coord;                  // HogCoordT<R>[]
     int coord_n = 0;
+    bool f64 = false;                // reference template parameter T = double
+    size_t rs = sizeof(float);       // sizeof(T)
 
     // plans
     std::vector<std::unique_ptr<Plan>> plans;
@@ -349,15 +352,29 @@ int get_image_plan(pbd_handle *h, int rows, int cols, int cn, Plan **out)
     // HOG coordinate table grows with the largest frame seen
     const int need = std::max(rows, cols) + 4 * h->sbin + 8;
     if (need > h->coord_n) {
-        std::vector<HogCoord> coord(need);
-        for (int t = 0; t < need; ++t) {   // HOGFeatures.cpp:252-259, T=float
-            const float tp = (float)(((double)(float)t + 0.5) / (double)(float)h->sbin - 0.5);
-            const int ip = (int)floorf(tp);
-            const float v0 = tp - (float)ip;
-            const float v1 = (float)(1.0 - (double)v0);
-            coord[t] = {ip, v0, v1};
+        // HOGFeatures.cpp:252-259: yp = ((T)y+0.5)/(T)sbin - 0.5; iyp = floor(yp); vy0 = yp-iyp; vy1 = 1.0-vy0
+        if (h->f64) {
+            std::vector<HogCoordD> coord(need);
+            for (int t = 0; t < need; ++t) {
+                const double tp = ((double)t + 0.5) / (double)h->sbin - 0.5;
+                const int ip = (int)floor(tp);
+                const double v0 = tp - (double)ip;
+                coord[t] = {ip, v0, 1.0 - v0};
+            }
+            HIPCHK(h, h->d_coord.ensure(coord.size() * sizeof(HogCoordD)));
+            HIPCHK(h, hipMemcpy(h->d_coord.p, coord.data(), coord.size() * sizeof(HogCoordD), hipMemcpyHostToDevice));
+        } else {
+            std::vector<HogCoord> coord(need);
+            for (int t = 0; t < need; ++t) {
+                const float tp = (float)(((double)(float)t + 0.5) / (double)(float)h->sbin - 0.5);
+                const int ip = (int)floorf(tp);
+                const float v0 = tp - (float)ip;
+                const float v1 = (float)(1.0 - (double)v0);
+                coord[t] = {ip, v0, v1};
+            }
+            HIPCHK(h, h->d_coord.ensure(coord.size() * sizeof(HogCoord)));
+            HIPCHK(h, hipMemcpy(h->d_coord.p, coord.data(), coord.size() * sizeof(HogCoord), hipMemcpyHostToDevice));
         }
-        HIPCHK(h, h->d_coord.upload(coord));
         h->coord_n = need;
     }
     *out = P.get();
@@ -397,7 +414,8 @@ int get_dims_plan(pbd_handle *h, int nlevels, const int *rows, const int *cols, 
 }
 
 // ---- model tables --------------------------------------------------------------------------------
-int upload_filters(pbd_handle *h, int nfilters, const float *const *filters, const int *ksize)
+template <typename R>
+int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize)
 {
     if (nfilters <= 0) return fail(h, PBD_ERR_INVALID, "no filters");
     const int K = ksize[0];
@@ -405,21 +423,30 @@ int upload_filters(pbd_handle *h, int nfilters, const float *const *filters, con
         if (ksize[f] != K) return fail(h, PBD_ERR_UNSUPPORTED, "filters of different sizes (%d vs %d) are not supported", ksize[f], K);
     if (K < 1 || K > 7) return fail(h, PBD_ERR_UNSUPPORTED, "filter size %d not supported (1..7)", K);
     const int Fpad = (nfilters + kConvQ - 1) / kConvQ * kConvQ;
-    // device layout: 5x5 kernel [group][channel][tap][8] (800 contiguous bytes per (group, channel));
-    // generic kernel [channel][tap][Fpad]
-    std::vector<float> w((size_t)32 * K * K * Fpad, 0.f);
-    for (int f = 0; f < nfilters; ++f)
+    // device layout: float 5x5 kernel [group][channel][tap][8] (800 contiguous bytes per (group, channel));
+    // generic kernel (other sizes, T=double) [channel][tap][Fpad]
+    const bool fast = (sizeof(R) == 4 && K == 5);
+    std::vector<R> w((size_t)32 * K * K * Fpad, (R)0);
+    for (int f = 0; f < nfilters; ++f) {
+        const R *src = static_cast<const R *>(filters[f]);
         for (int t = 0; t < K * K; ++t)
             for (int c = 0; c < 32; ++c) {
-                const float v = filters[f][(size_t)t * 32 + c];
-                if (K == 5) w[(((size_t)(f / kConvQ) * 32 + c) * K * K + t) * kConvQ + (f % kConvQ)] = v;
+                const R v = src[(size_t)t * 32 + c];
+                if (fast) w[(((size_t)(f / kConvQ) * 32 + c) * K * K + t) * kConvQ + (f % kConvQ)] = v;
                 else w[((size_t)c * K * K + t) * Fpad + f] = v;
             }
-    HIPCHK(h, h->d_wts.upload(w));
+    }
+    HIPCHK(h, h->d_wts.ensure(w.size() * sizeof(R)));
+    HIPCHK(h, hipMemcpy(h->d_wts.p, w.data(), w.size() * sizeof(R), hipMemcpyHostToDevice));
     h->F = nfilters; h->Fpad = Fpad; h->ksize = K;
     h->filter_ksize.assign(ksize, ksize + nfilters);
     h->filters_set = true;
     return PBD_OK;
+}
+
+int upload_filters(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize)
+{
+    return h->f64 ? upload_filters_t<double>(h, nfilters, filters, ksize) : upload_filters_t<float>(h, nfilters, filters, ksize);
 }
 
 int build_model(pbd_handle *h, const pbd_model *m)
@@ -444,8 +471,11 @@ int build_model(pbd_handle *h, const pbd_model *m)
 
     // filters
     {
-        std::vector<const float *> fp(m->nfilters);
-        for (int f = 0; f < m->nfilters; ++f) fp[f] = m->filters_f32 + m->filter_offset[f];
+        if (h->f64 ? !m->filters_f64 : !m->filters_f32) return fail(h, PBD_ERR_INVALID, "model has no filters of the requested real type");
+        std::vector<const void *> fp(m->nfilters);
+        for (int f = 0; f < m->nfilters; ++f)
+            fp[f] = h->f64 ? static_cast<const void *>(m->filters_f64 + m->filter_offset[f])
+                           : static_cast<const void *>(m->filters_f32 + m->filter_offset[f]);
         int rc = upload_filters(h, m->nfilters, fp.data(), m->filter_ksize);
         if (rc != PBD_OK) return rc;
     }
@@ -581,9 +611,9 @@ int build_model(pbd_handle *h, const pbd_model *m)
 int alloc_features(pbd_handle *h, Plan &P, int nframes)
 {
     HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * P.cn));
-    HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * sizeof(float)));
-    HIPCHK(h, h->norm.ensure((size_t)nframes * P.blk_per_frame * sizeof(float)));
-    HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * 32 * sizeof(float), 16)));
+    HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * h->rs));
+    HIPCHK(h, h->norm.ensure((size_t)nframes * P.blk_per_frame * h->rs));
+    HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * 32 * h->rs, 16)));
     return PBD_OK;
 }
 
@@ -608,22 +638,22 @@ void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int f0, int n
     HogParams hp{};
     hp.lv = P.d_lv.d; hp.nlevels = P.nlevels; hp.cn = cn; hp.sbin = h->sbin; hp.frame0 = f0;
     hp.pix_per_frame = P.pix_per_frame; hp.blk_per_frame = P.blk_per_frame; hp.cell_per_frame = P.cell_per_frame;
-    hp.pyr = h->pyr.as<uint8_t>(); hp.coord = h->d_coord.d;
-    hp.hist = h->hist.as<float>(); hp.norm = h->norm.as<float>(); hp.feat = h->feat.as<float>();
+    hp.pyr = h->pyr.as<uint8_t>(); hp.coord = h->d_coord.p;
+    hp.hist = h->hist.p; hp.norm = h->norm.p; hp.feat = h->feat.p;
     {
         ProfScope ps(h, PBD_K_HOG_HIST, st);
-        launch_hog_hist(hp, nb, st);
+        launch_hog_hist(hp, nb, h->f64, st);
     }
     {
         ProfScope ps(h, PBD_K_HOG_FEAT, st);
-        launch_hog_feat(hp, nb, st);
+        launch_hog_feat(hp, nb, h->f64, st);
     }
 }
 
 int alloc_conv(pbd_handle *h, Plan &P, int nframes)
 {
     if (!h->filters_set) return fail(h, PBD_ERR_STATE, "pdf() before setFilters()");
-    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * h->F * sizeof(float), 16)));
+    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * h->F * h->rs, 16)));
     return PBD_OK;
 }
 
@@ -637,10 +667,10 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     const long long wgs = (long long)P.ntiles * nb;
     cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
     cp.cell_per_frame = P.cell_per_frame;
-    cp.feat = h->feat.as<float>(); cp.wts = h->d_wts.d; cp.resp = h->resp.as<float>();
+    cp.feat = h->feat.p; cp.wts = h->d_wts.p; cp.resp = h->resp.p;
     cp.fma = h->cfg.conv_mode == PBD_CONV_FMA;
     ProfScope ps(h, PBD_K_CONV, st);
-    launch_conv(cp, nb, st);
+    launch_conv(cp, nb, h->f64, st);
 }
 
 // frames per DP chunk so that the chunk scratch stays within the budget
@@ -650,7 +680,7 @@ int dp_chunk_frames(pbd_handle *h, Plan &P, int want)
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     const size_t budget = (size_t)8 << 30;   // bytes of scratch per chunk (14 B / cell-job + 12 B / stack entry)
     int chunk = std::max(want, 1);
-    while (chunk > 1 && (per_frame * 14 + stk_per_frame * 12) * chunk > budget) chunk = (chunk + 1) / 2;
+    while (chunk > 1 && (per_frame * (6 + 2 * h->rs) + stk_per_frame * (h->f64 ? kStkEntryF64 : kStkEntryF32)) * chunk > budget) chunk = (chunk + 1) / 2;
     return chunk;
 }
 
@@ -658,19 +688,19 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
 {
     const size_t cpf = (size_t)P.cell_per_frame;
     const int NSa = std::max(h->NS, 1);
-    HIPCHK(h, h->msg.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(float), 16)));
+    HIPCHK(h, h->msg.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * h->rs, 16)));
     HIPCHK(h, h->Ix.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(int16_t), 16)));
     HIPCHK(h, h->Iy.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(int16_t), 16)));
     HIPCHK(h, h->Ik.ensure(std::max<size_t>((size_t)nframes * cpf * NSa, 16)));
-    HIPCHK(h, h->rootv.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(float), 16)));
+    HIPCHK(h, h->rootv.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * h->rs, 16)));
     HIPCHK(h, h->rooti.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(int), 16)));
     const size_t per_frame = cpf * std::max(h->JGmax, 1);
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
-    HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
-    HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * sizeof(float), 16)));
+    HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
+    HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
     HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int), 16)));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
-    HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * 12, 16)));
+    HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkEntryF64 : kStkEntryF32), 16)));
     return PBD_OK;
 }
 
@@ -680,25 +710,25 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     DpParams dp{};
     dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC;
     dp.cell_per_frame = P.cell_per_frame;
-    dp.resp = h->resp.as<float>(); dp.msg = h->msg.as<float>();
+    dp.resp = h->resp.p; dp.msg = h->msg.p;
     dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
-    dp.tmp = h->tmp.as<float>(); dp.dt = h->dt.as<float>();
+    dp.tmp = h->tmp.p; dp.dt = h->dt.p;
     dp.IxRaw32 = h->IxRaw.as<int>(); dp.IyRaw = h->IyRaw.as<int16_t>();
     dp.stk = h->stk.p; dp.stk_per_jf = P.stk_per_jf;
     dp.stk_row_off = P.d_stk_row_off.d; dp.stk_col_off = P.d_stk_col_off.d;
     dp.child_slots = h->d_child_slots.d; dp.biasw = h->d_biasw.d;
     dp.row2level = P.d_row2level.d; dp.rowoff = P.d_rowoff.d; dp.col2level = P.d_col2level.d; dp.coloff = P.d_coloff.d;
     dp.nrows_flat = P.nrows_flat; dp.ncols_flat = P.ncols_flat;
-    dp.rootv = h->rootv.as<float>(); dp.rooti = h->rooti.as<int>(); dp.rjobs = h->d_rjobs.d;
+    dp.rootv = h->rootv.p; dp.rooti = h->rooti.as<int>(); dp.rjobs = h->d_rjobs.d;
     dp.frame0 = f0;
     for (auto &g : h->groups) {
         dp.JG = (int)g.jobs.size();
         dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d;
-        { ProfScope ps(h, PBD_K_DT_ROWS, st); launch_dt_rows(dp, nb, st); }
-        { ProfScope ps(h, PBD_K_DT_COLS, st); launch_dt_cols(dp, nb, st); }
-        { ProfScope ps(h, PBD_K_DP_COMBINE, st); launch_dp_combine(dp, (int)g.cjobs.size(), nb, st); }
+        { ProfScope ps(h, PBD_K_DT_ROWS, st); launch_dt_rows(dp, nb, h->f64, st); }
+        { ProfScope ps(h, PBD_K_DT_COLS, st); launch_dt_cols(dp, nb, h->f64, st); }
+        { ProfScope ps(h, PBD_K_DP_COMBINE, st); launch_dp_combine(dp, (int)g.cjobs.size(), nb, h->f64, st); }
     }
-    { ProfScope ps(h, PBD_K_DP_ROOT, st); launch_dp_root(dp, nb, st); }
+    { ProfScope ps(h, PBD_K_DP_ROOT, st); launch_dp_root(dp, nb, h->f64, st); }
 }
 
 // single-stream wrappers used by the staged entry points
@@ -743,7 +773,7 @@ int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32
     ArgminParams ap{};
     ap.lv = P.d_lv.d; ap.nlevels = P.nlevels; ap.NS = h->NS; ap.NC = h->NC; ap.nframes = nframes;
     ap.cell_per_frame = P.cell_per_frame;
-    ap.rootv = h->rootv.as<float>(); ap.rooti = h->rooti.as<int>();
+    ap.rootv = h->rootv.p; ap.rooti = h->rooti.as<int>();
     ap.Ix = h->Ix.as<int16_t>(); ap.Iy = h->Iy.as<int16_t>(); ap.Ik = h->Ik.as<uint8_t>();
     ap.thresh = h->thresh; ap.scales = d_scales;
     ap.walk = h->d_walk.d; ap.walk_off = h->d_walk_off.d;
@@ -752,7 +782,7 @@ int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32
     int found = 0;
     {
         ProfScope ps(h, PBD_K_ARGMIN, h->stream);
-        launch_argmin_find(ap, h->stream);
+        launch_argmin_find(ap, h->f64, h->stream);
     }
     HIPCHK(h, hipMemcpyAsync(&found, h->count.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -761,7 +791,7 @@ int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32
     if (n > 0) {
         {
             ProfScope ps(h, PBD_K_ARGMIN, h->stream);
-            launch_argmin_walk(ap, n, h->stream);
+            launch_argmin_walk(ap, n, h->f64, h->stream);
         }
         h->cand_host.resize((size_t)n * stride);
         HIPCHK(h, hipMemcpyAsync(h->cand_host.data(), h->cand.p, (size_t)n * stride * sizeof(int32_t), hipMemcpyDeviceToHost,
@@ -872,8 +902,8 @@ int pbd_create(const pbd_model *model, const pbd_config *config, pbd_handle **ou
 {
     if (!model || !config || !out) return fail(nullptr, PBD_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (config->real_type != PBD_REAL_F32)
-        return fail(nullptr, PBD_ERR_UNSUPPORTED, "real_type %d: only PBD_REAL_F32 is built", config->real_type);
+    if (config->real_type != PBD_REAL_F32 && config->real_type != PBD_REAL_F64)
+        return fail(nullptr, PBD_ERR_UNSUPPORTED, "real_type %d: PBD_REAL_F32 or PBD_REAL_F64", config->real_type);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev < 1)
@@ -884,6 +914,8 @@ int pbd_create(const pbd_model *model, const pbd_config *config, pbd_handle **ou
     if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     auto h = std::make_unique<pbd_handle>();
     h->cfg = *config;
+    h->f64 = config->real_type == PBD_REAL_F64;
+    h->rs = h->f64 ? sizeof(double) : sizeof(float);
     if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
     if (h->cfg.max_candidates < 1) h->cfg.max_candidates = 65536;
     if (config->stream) {
@@ -918,8 +950,8 @@ void pbd_destroy(pbd_handle *h)
                       &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();
-    h->d_wts.release(); h->d_biasw.release(); h->d_child_slots.release(); h->d_walk_off.release();
-    h->d_rjobs.release(); h->d_walk.release(); h->d_coord.release();
+    h->d_wts.release(); h->d_biasw.release(); h->d_coord.release(); h->d_child_slots.release(); h->d_walk_off.release();
+    h->d_rjobs.release(); h->d_walk.release();
     for (auto &g : h->groups) { g.d_jobs.release(); g.d_cjobs.release(); }
     h->plans.clear();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -957,7 +989,7 @@ int pbd_pyramid_plan(pbd_handle *h, int rows, int cols, int *nlevels, int *img_r
 }
 
 int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int channels, size_t stride_bytes,
-                         int depth_code, float *const *feat)
+                         int depth_code, void *const *feat)
 {
     if (!h || !img || !feat) return PBD_ERR_INVALID;
     (void)hipSetDevice(h->cfg.device);
@@ -974,7 +1006,7 @@ int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int
         const LevelDesc &d = P->lv[l];
         const size_t n = (size_t)d.rows * d.cols * 32;
         if (n && feat[l])
-            HIPCHK(h, hipMemcpyAsync(feat[l], h->feat.as<float>() + (size_t)d.cell_off * 32, n * sizeof(float),
+            HIPCHK(h, hipMemcpyAsync(feat[l], h->feat.as<char>() + (size_t)d.cell_off * 32 * h->rs, n * h->rs,
                                      hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -995,7 +1027,7 @@ int pbd_get_pyramid_image(pbd_handle *h, int frame, int level, uint8_t *dst)
     return PBD_OK;
 }
 
-int pbd_conv_set_filters(pbd_handle *h, int nfilters, const float *const *filters, const int *ksize)
+int pbd_conv_set_filters(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize)
 {
     if (!h || !filters || !ksize) return PBD_ERR_INVALID;
     (void)hipSetDevice(h->cfg.device);
@@ -1003,42 +1035,42 @@ int pbd_conv_set_filters(pbd_handle *h, int nfilters, const float *const *filter
     return upload_filters(h, nfilters, filters, ksize);
 }
 
-int pbd_conv_pdf(pbd_handle *h, int nlevels, const float *const *feat, const int *rows, const int *cols, float *const *resp)
+int pbd_conv_pdf(pbd_handle *h, int nlevels, const void *const *feat, const int *rows, const int *cols, void *const *resp)
 {
     if (!h || !feat || !rows || !cols || !resp) return PBD_ERR_INVALID;
     (void)hipSetDevice(h->cfg.device);
     Plan *P = nullptr;
     int rc = get_dims_plan(h, nlevels, rows, cols, &P);
     if (rc != PBD_OK) return rc;
-    HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)P->cell_per_frame * 32 * sizeof(float), 16)));
+    HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)P->cell_per_frame * 32 * h->rs, 16)));
     for (int l = 0; l < nlevels; ++l) {
         const size_t n = (size_t)rows[l] * cols[l] * 32;
-        if (n) HIPCHK(h, hipMemcpyAsync(h->feat.as<float>() + (size_t)P->lv[l].cell_off * 32, feat[l], n * sizeof(float),
+        if (n) HIPCHK(h, hipMemcpyAsync(h->feat.as<char>() + (size_t)P->lv[l].cell_off * 32 * h->rs, feat[l], n * h->rs,
                                         hipMemcpyHostToDevice, h->stream));
     }
     h->cur = P; h->cur_frames = 1; h->have_features = true; h->have_resp = h->have_dp = false;
     if ((rc = run_conv(h, *P, 1)) != PBD_OK) return rc;
     for (int l = 0; l < nlevels; ++l) {
         const size_t n = (size_t)rows[l] * cols[l] * h->F;
-        if (n) HIPCHK(h, hipMemcpyAsync(resp[l], h->resp.as<float>() + (size_t)P->lv[l].cell_off * h->F, n * sizeof(float),
+        if (n) HIPCHK(h, hipMemcpyAsync(resp[l], h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->rs, n * h->rs,
                                         hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PBD_OK;
 }
 
-int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, const float *const *resp, int32_t *const *Ix,
-               int32_t *const *Iy, int32_t *const *Ik, float *const *rootv, int32_t *const *rooti)
+int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, const void *const *resp, int32_t *const *Ix,
+               int32_t *const *Iy, int32_t *const *Ik, void *const *rootv, int32_t *const *rooti)
 {
     if (!h || !rows || !cols || !resp) return PBD_ERR_INVALID;
     (void)hipSetDevice(h->cfg.device);
     Plan *P = nullptr;
     int rc = get_dims_plan(h, nlevels, rows, cols, &P);
     if (rc != PBD_OK) return rc;
-    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)P->cell_per_frame * h->F * sizeof(float), 16)));
+    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)P->cell_per_frame * h->F * h->rs, 16)));
     for (int l = 0; l < nlevels; ++l) {
         const size_t n = (size_t)rows[l] * cols[l] * h->F;
-        if (n) HIPCHK(h, hipMemcpyAsync(h->resp.as<float>() + (size_t)P->lv[l].cell_off * h->F, resp[l], n * sizeof(float),
+        if (n) HIPCHK(h, hipMemcpyAsync(h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->rs, resp[l], n * h->rs,
                                         hipMemcpyHostToDevice, h->stream));
     }
     h->cur = P; h->cur_frames = 1; h->have_resp = true; h->have_dp = false;
@@ -1066,7 +1098,7 @@ int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, con
             }
         }
         const size_t roff = (size_t)P->lv[l].cell_off * h->NC;
-        if (rootv && rootv[l]) HIPCHK(h, hipMemcpy(rootv[l], h->rootv.as<float>() + roff, hw * h->NC * sizeof(float), hipMemcpyDeviceToHost));
+        if (rootv && rootv[l]) HIPCHK(h, hipMemcpy(rootv[l], h->rootv.as<char>() + roff * h->rs, hw * h->NC * h->rs, hipMemcpyDeviceToHost));
         if (rooti && rooti[l]) HIPCHK(h, hipMemcpy(rooti[l], h->rooti.as<int>() + roff, hw * h->NC * sizeof(int), hipMemcpyDeviceToHost));
     }
     return PBD_OK;
@@ -1124,13 +1156,13 @@ int pbd_get_stage(pbd_handle *h, int stage, int frame, int level, void *dst, siz
     switch (stage) {
     case PBD_STAGE_FEATURES:
         if (!h->have_features) return fail(h, PBD_ERR_STATE, "features not computed");
-        src = h->feat.as<float>() + ((size_t)frame * cpf + d.cell_off) * 32; bytes = hw * 32 * sizeof(float); break;
+        src = h->feat.as<char>() + ((size_t)frame * cpf + d.cell_off) * 32 * h->rs; bytes = hw * 32 * h->rs; break;
     case PBD_STAGE_RESPONSES:
         if (!h->have_resp) return fail(h, PBD_ERR_STATE, "responses not computed");
-        src = h->resp.as<float>() + ((size_t)frame * cpf + d.cell_off) * h->F; bytes = hw * h->F * sizeof(float); break;
+        src = h->resp.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->F * h->rs; bytes = hw * h->F * h->rs; break;
     case PBD_STAGE_ROOTV:
         if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
-        src = h->rootv.as<float>() + ((size_t)frame * cpf + d.cell_off) * h->NC; bytes = hw * h->NC * sizeof(float); break;
+        src = h->rootv.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->NC * h->rs; bytes = hw * h->NC * h->rs; break;
     case PBD_STAGE_ROOTI:
         if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
         src = h->rooti.as<int>() + ((size_t)frame * cpf + d.cell_off) * h->NC; bytes = hw * h->NC * sizeof(int); break;

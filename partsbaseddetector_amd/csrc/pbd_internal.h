@@ -30,7 +30,9 @@ struct ResizeTabX { int sx; short a0, a1; };
 struct ResizeTabY { int y0, y1; short b0, b1; };
 
 // bilinear cell weights of a pixel coordinate (src/HOGFeatures.cpp:252-259), depends on sbin only
-struct HogCoord { int ip; float v0, v1; };
+template <typename R> struct HogCoordT { int ip; R v0, v1; };
+typedef HogCoordT<float> HogCoord;
+typedef HogCoordT<double> HogCoordD;
 
 struct ConvTile { int level; int y0, x0; };
 
@@ -65,6 +67,8 @@ struct PartWalk {             // argmin tree walk, one per part of a component
 };
 
 constexpr int kMaxMix = 8;
+// bytes of one spilled envelope-stack entry {T z; T s; int v;} (natural alignment of T)
+constexpr size_t kStkEntryF32 = 12, kStkEntryF64 = 24;
 constexpr int kConvTW = 32, kConvTH = 8, kConvQ = 8;
 
 // ---- launch parameter blocks ---------------------------------------------------------------
@@ -86,10 +90,10 @@ struct HogParams {
     int frame0;
     long long pix_per_frame, blk_per_frame, cell_per_frame;
     const uint8_t *pyr;
-    const HogCoord *coord;
-    float *hist;                  // [frames][18][blk_per_frame]
-    float *norm;                  // [frames][blk_per_frame]
-    float *feat;                  // [frames][cell_per_frame*32]
+    const void *coord;            // HogCoordT<R>[]
+    void *hist;                   // R [frames][18][blk_per_frame]
+    void *norm;                   // R [frames][blk_per_frame]
+    void *feat;                   // R [frames][cell_per_frame*32]
 };
 
 struct ConvParams {
@@ -100,9 +104,9 @@ struct ConvParams {
     int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
     int frame0;
     long long cell_per_frame;
-    const float *feat;            // [frames][cell_per_frame*32]
-    const float *wts;             // [32][k*k][Fpad]
-    float *resp;                  // [frames][cell_per_frame*F], level-major then filter planes
+    const void *feat;             // R [frames][cell_per_frame*32]
+    const void *wts;              // R; 5x5 float kernel: [group][32][tap][8]; generic: [32][k*k][Fpad]
+    void *resp;                   // R [frames][cell_per_frame*F], level-major then filter planes
     int fma;
 };
 
@@ -112,13 +116,13 @@ struct DpParams {
     int F, NS, NC;                // filters, pointer slots, components
     long long cell_per_frame;
     int frame0;                   // first frame of this chunk (absolute index into resp/msg/ptr buffers)
-    const float *resp;
-    float *msg;                   // [frames][cell_per_frame*NS]
+    const void *resp;             // R
+    void *msg;                    // R [frames][cell_per_frame*NS]
     int16_t *Ix, *Iy;             // [frames][cell_per_frame*NS]
     uint8_t *Ik;
     // group scratch, indexed by chunk-local frame
     int JG;                       // jobs in this group
-    float *tmp, *dt;              // [chunk][cell_per_frame*JG]
+    void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
     int *IxRaw32; int16_t *IyRaw;
     void *stk;                    // [chunk][JG][stk_per_jf] 12-byte entries, wave-private, lane-interleaved
     long long stk_per_jf;         // entries per (job, frame)
@@ -131,7 +135,7 @@ struct DpParams {
     const int *row2level; const int *rowoff;   // flat row -> level, level -> first flat row
     const int *col2level; const int *coloff;
     int nrows_flat, ncols_flat;
-    float *rootv; int *rooti;     // [frames][cell_per_frame*NC]
+    void *rootv; int *rooti;      // R / int [frames][cell_per_frame*NC]
     const RootJob *rjobs;
 };
 
@@ -139,7 +143,7 @@ struct ArgminParams {
     const LevelDesc *lv;
     int nlevels, NS, NC, nframes;
     long long cell_per_frame;
-    const float *rootv; const int *rooti;
+    const void *rootv; const int *rooti;   // rootv: R
     const int16_t *Ix, *Iy; const uint8_t *Ik;
     float thresh;
     const float *scales;          // [nlevels]
@@ -154,15 +158,16 @@ struct ArgminParams {
 void launch_resize(const PyrParams &p, int nframes, long long npix_resized, hipStream_t s);
 void launch_pyrdown_range(const PyrParams &p, int nframes, int first_level, int last_level, long long base,
                           long long npix, hipStream_t s);
-void launch_hog_hist(const HogParams &p, int nframes, hipStream_t s);
-void launch_hog_feat(const HogParams &p, int nframes, hipStream_t s);
-void launch_conv(const ConvParams &p, int nframes, hipStream_t s);
+// `f64` selects the reference's T=double instantiation (every real-typed buffer then holds doubles)
+void launch_hog_hist(const HogParams &p, int nframes, bool f64, hipStream_t s);
+void launch_hog_feat(const HogParams &p, int nframes, bool f64, hipStream_t s);
+void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s);
 int conv_occupancy(int nw);
-void launch_dt_rows(const DpParams &p, int nframes, hipStream_t s);
-void launch_dt_cols(const DpParams &p, int nframes, hipStream_t s);
-void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, hipStream_t s);
-void launch_dp_root(const DpParams &p, int nframes, hipStream_t s);
-void launch_argmin_find(const ArgminParams &p, hipStream_t s);
-void launch_argmin_walk(const ArgminParams &p, int ncand, hipStream_t s);
+void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s);
+void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s);
+void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hipStream_t s);
+void launch_dp_root(const DpParams &p, int nframes, bool f64, hipStream_t s);
+void launch_argmin_find(const ArgminParams &p, bool f64, hipStream_t s);
+void launch_argmin_walk(const ArgminParams &p, int ncand, bool f64, hipStream_t s);
 
 }  // namespace pbd

@@ -149,11 +149,13 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p
     }
 }
 
-// generic filter size (no unrolling); used for models whose filters are not 5x5
-template <bool FMA>
+// generic kernel: any filter size, any real type R (the reference's T=double instantiation runs here);
+// one output pixel per thread, weights [channel][tap][Fpad] read with wave-uniform vector loads
+template <typename R, bool FMA>
 __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
 {
-    extern __shared__ float smd[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    R *smd = reinterpret_cast<R *>(smraw);
     constexpr int TW = kConvTW, TH = kConvTH, Q = kConvQ;
     const int K = p.ksize;
     const int PW = TW + K - 1, PH = TH + K - 1;
@@ -164,14 +166,15 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
     const int H = d.rows, W = d.cols;
     const int a = K / 2;
     const int t = threadIdx.x;
-    const float *feat = p.feat + ((size_t)frame * p.cell_per_frame + d.cell_off) * 32;
+    const R *feat = static_cast<const R *>(p.feat) + ((size_t)frame * p.cell_per_frame + d.cell_off) * 32;
+    const R *wts = static_cast<const R *>(p.wts);
     {
         const int c = t & 31;
-        const float border = (c == 31) ? 1.0f : 0.0f;
+        const R border = (c == 31) ? (R)1 : (R)0;
         for (int ci = t >> 5; ci < PH * PW; ci += 8) {
             const int cy = ci / PW, cx = ci - cy * PW;
             const int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
-            float v = border;
+            R v = border;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = feat[((size_t)gy * W + gx) * 32 + c];
             smd[c * PLANE + ci] = v;
         }
@@ -184,24 +187,24 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
     const int g0 = blockIdx.y * p.groups_per_block;
     const int g1 = min(g0 + p.groups_per_block, ngroups);
     const size_t HW = (size_t)H * W;
-    float *resp = p.resp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)y * W + x;
+    R *resp = static_cast<R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)y * W + x;
     for (int g = g0; g < g1; ++g) {
-        float r[Q];
+        R r[Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) r[q] = 0.0f;
+        for (int q = 0; q < Q; ++q) r[q] = (R)0;
         for (int c = 0; c < 32; ++c) {
-            const float *sp = smd + c * PLANE + py * PW + px;
-            const float *wp = p.wts + (size_t)c * (K * K) * p.Fpad + g * Q;
-            float s[Q];
+            const R *sp = smd + c * PLANE + py * PW + px;
+            const R *wp = wts + (size_t)c * (K * K) * p.Fpad + g * Q;
+            R s[Q];
 #pragma unroll
-            for (int q = 0; q < Q; ++q) s[q] = 0.0f;
+            for (int q = 0; q < Q; ++q) s[q] = (R)0;
             for (int i = 0; i < K; ++i) {
                 for (int j = 0; j < K; ++j) {
-                    const float f = sp[i * PW + j];
-                    const float *w = wp + (size_t)(i * K + j) * p.Fpad;
+                    const R f = sp[i * PW + j];
+                    const R *w = wp + (size_t)(i * K + j) * p.Fpad;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
-                        if (FMA) s[q] = __fmaf_rn(w[q], f, s[q]);
+                        if (FMA) s[q] = __builtin_fma(w[q], f, s[q]);
                         else s[q] = s[q] + w[q] * f;
                     }
                 }
@@ -228,30 +231,40 @@ int conv_occupancy(int nw)
     return n;
 }
 
-void launch_conv(const ConvParams &p, int nframes, hipStream_t s)
+template <typename R, bool FMA>
+static void launch_generic(const ConvParams &p, dim3 grid, hipStream_t s)
+{
+    const int PW = kConvTW + p.ksize - 1, PH = kConvTH + p.ksize - 1;
+    const size_t lds = (size_t)32 * ((PH * PW) | 1) * sizeof(R);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_generic<R, FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_conv_generic<R, FMA>), grid, dim3(256), lds, s, p);
+}
+
+void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.ntiles == 0 || p.F == 0) return;
     const int ngroups = p.Fpad / kConvQ;
     const int gy = (ngroups + p.groups_per_block - 1) / p.groups_per_block;
     dim3 grid(p.ntiles, gy, nframes);
-    if (p.ksize == 5) {
+    if (!f64 && p.ksize == 5) {
         // waves per workgroup: prefer a count that divides the groups of a workgroup evenly
         const int gb = std::min(p.groups_per_block, ngroups);
         const int nw = (gb % 5 == 0) ? 5 : (gb % 6 == 0) ? 6 : (gb % 4 == 0) ? 4 : 5;
-#define PBD_LAUNCH_CONV(NW)                                                                                      \
-    do {                                                                                                         \
-        if (p.fma) hipLaunchKernelGGL((k_conv<5, true, NW>), grid, dim3(NW * 64), 0, s, p, p.wts, p.feat, p.resp); \
-        else hipLaunchKernelGGL((k_conv<5, false, NW>), grid, dim3(NW * 64), 0, s, p, p.wts, p.feat, p.resp);      \
+        const float *w = static_cast<const float *>(p.wts), *ft = static_cast<const float *>(p.feat);
+        float *rp = static_cast<float *>(p.resp);
+#define PBD_LAUNCH_CONV(NW)                                                                            \
+    do {                                                                                               \
+        if (p.fma) hipLaunchKernelGGL((k_conv<5, true, NW>), grid, dim3(NW * 64), 0, s, p, w, ft, rp);  \
+        else hipLaunchKernelGGL((k_conv<5, false, NW>), grid, dim3(NW * 64), 0, s, p, w, ft, rp);       \
     } while (0)
         if (nw == 5) PBD_LAUNCH_CONV(5);
         else if (nw == 6) PBD_LAUNCH_CONV(6);
         else PBD_LAUNCH_CONV(4);
 #undef PBD_LAUNCH_CONV
+    } else if (f64) {
+        if (p.fma) launch_generic<double, true>(p, grid, s); else launch_generic<double, false>(p, grid, s);
     } else {
-        const int PW = kConvTW + p.ksize - 1, PH = kConvTH + p.ksize - 1;
-        const size_t lds = (size_t)32 * ((PH * PW) | 1) * sizeof(float);
-        if (p.fma) hipLaunchKernelGGL((k_conv_generic<true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((k_conv_generic<false>), grid, dim3(256), lds, s, p);
+        if (p.fma) launch_generic<float, true>(p, grid, s); else launch_generic<float, false>(p, grid, s);
     }
 }
 

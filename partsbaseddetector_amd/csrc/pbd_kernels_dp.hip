@@ -16,25 +16,21 @@
 
 namespace pbd {
 
-__device__ __forceinline__ float quad_isect(double a, double b, int x0, int x1, float y0f, float y1f)
+template <typename R>
+__device__ __forceinline__ R quad_isect(double a, double b, int x0, int x1, R y0f, R y1f)
 {   // Quadratic::operator()(x0, x1, y0, y1), include/DistanceTransform.hpp:98-100, rounded to T
     const double y0 = (double)y0f, y1 = (double)y1f;
     const double num = ((y1 - y0) - b * (double)(x1 - x0)) + a * (double)(x1 * x1 - x0 * x0);
-    return (float)(num / ((2 * a) * (double)(x1 - x0)));
+    return (R)(num / ((2 * a) * (double)(x1 - x0)));
 }
-__device__ __forceinline__ float quad_val(double a, double b, int x, float y)
+template <typename R>
+__device__ __forceinline__ R quad_val(double a, double b, int x, R y)
 {   // Quadratic::operator()(x, y), :103-105
-    return (float)((a * (double)(x * x) + b * (double)x) + (double)y);
+    return (R)((a * (double)(x * x) + b * (double)x) + (double)y);
 }
-
-// input of a DT job at one cell: raw response + children's messages in descending child order
-__device__ __forceinline__ float dt_input(const float *resp_plane, const float *msg_base, size_t HW, size_t off,
-                                          const int *child_slots, int cb, int ce)
-{
-    float v = resp_plane[off];
-    for (int k = cb; k < ce; ++k) v = v + msg_base[(size_t)child_slots[k] * HW + off];
-    return v;
-}
+template <typename R> struct RealLimits;
+template <> struct RealLimits<float> { static __device__ __forceinline__ float inf() { return INFINITY; } };
+template <> struct RealLimits<double> { static __device__ __forceinline__ double inf() { return (double)INFINITY; } };
 
 // ------------------------------------------------------------------------------------------------
 // One 1-D transform per thread, streamed in chunks of CH elements.
@@ -50,45 +46,47 @@ __device__ __forceinline__ float dt_input(const float *resp_plane, const float *
 //   * source values are prefetched one chunk ahead and results leave in whole chunks.
 // The arithmetic per element is exactly computeRow's (DistanceTransform.hpp:152-182).
 // ------------------------------------------------------------------------------------------------
-struct __attribute__((aligned(4))) StkEntry { float z; float s; int v; };
+template <typename R> struct StkEntryT { R z; R s; int v; };
+static_assert(sizeof(StkEntryT<float>) == kStkEntryF32 && sizeof(StkEntryT<double>) == kStkEntryF64, "host sizes the spill stack with these");
 
 constexpr int kDtCH = 8;
 constexpr int kDtT = 16;    // ring entries per lane
 
+template <typename R>
 struct DtRing {
-    float *z; float *s; int *v;   // this lane's column of the [T][64] arrays
-    StkEntry *g;                  // this lane's column of the global [k][lane] stack
+    R *z; R *s; int *v;           // this lane's column of the [T][64] arrays
+    StkEntryT<R> *g;              // this lane's column of the global [k][lane] stack
     int lo;                       // ring holds indices [lo, top)
-    __device__ __forceinline__ void push_below(int idx, float zk, float sk, int vk)
+    __device__ __forceinline__ void push_below(int idx, R zk, R sk, int vk)
     {   // entry `idx` (the old top) moves under a new top
         const int slot = idx & (kDtT - 1);
         if (idx - lo >= kDtT) {   // slot still holds live entry idx - T: spill it
-            g[(size_t)(idx - kDtT) * 64] = StkEntry{z[slot * 64], s[slot * 64], v[slot * 64]};
+            g[(size_t)(idx - kDtT) * 64] = StkEntryT<R>{z[slot * 64], s[slot * 64], v[slot * 64]};
             lo = idx - kDtT + 1;
         }
         z[slot * 64] = zk; s[slot * 64] = sk; v[slot * 64] = vk;
     }
-    __device__ __forceinline__ void pop(int idx, float &zk, float &sk, int &vk)
+    __device__ __forceinline__ void pop(int idx, R &zk, R &sk, int &vk)
     {   // entry `idx` becomes the top
         if (idx >= lo) {
             const int slot = idx & (kDtT - 1);
             zk = z[slot * 64]; sk = s[slot * 64]; vk = v[slot * 64];
         } else {
-            const StkEntry e = g[(size_t)idx * 64];
+            const StkEntryT<R> e = g[(size_t)idx * 64];
             zk = e.z; sk = e.s; vk = e.v;
             lo = idx;
         }
     }
 };
 
-template <class LoadChunk, class StoreChunk>
-__device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing ring, LoadChunk load, StoreChunk store)
+template <typename R, class LoadChunk, class StoreChunk>
+__device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store)
 {
     constexpr int CH = kDtCH;
-    float cur[CH], nxt[CH];
+    R cur[CH], nxt[CH];
     load(0, cur);
     int k = 0, vk = 0;
-    float zk = -INFINITY, sk = cur[0];
+    R zk = -RealLimits<R>::inf(), sk = cur[0];
     ring.lo = 0;
     for (int q0 = 0; q0 < N; q0 += CH) {
         if (q0 + CH < N) load(q0 + CH, nxt);
@@ -96,12 +94,12 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
         for (int i = 0; i < CH; ++i) {
             const int q = q0 + i;
             if (q >= 1 && q < N) {
-                const float sq = cur[i];
-                float s = quad_isect(a, b, vk, q, sk, sq);
+                const R sq = cur[i];
+                R s = quad_isect<R>(a, b, vk, q, sk, sq);
                 while (s <= zk && k > 0) {
                     --k;
                     ring.pop(k, zk, sk, vk);
-                    s = quad_isect(a, b, vk, q, sk, sq);
+                    s = quad_isect<R>(a, b, vk, q, sk, sq);
                 }
                 ring.push_below(k, zk, sk, vk);
                 ++k;
@@ -115,19 +113,19 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
     const int nch = (N + CH - 1) / CH;
     for (int cidx = nch - 1; cidx >= 0; --cidx) {
         const int q0 = cidx * CH;
-        float out[CH];
+        R out[CH];
         int ptr[CH];
 #pragma unroll
         for (int i = CH - 1; i >= 0; --i) {
-            out[i] = 0.f; ptr[i] = 0;
+            out[i] = (R)0; ptr[i] = 0;
             const int q = q0 + i;
             if (q < N) {
-                const float osf = (float)(os0 + q);
+                const R osf = (R)(os0 + q);
                 while (!(zk < osf)) {   // z[0] = -inf ends the walk
                     --k;
                     ring.pop(k, zk, sk, vk);
                 }
-                out[i] = quad_val(a, b, os0 + q - vk, sk);
+                out[i] = quad_val<R>(a, b, os0 + q - vk, sk);
                 ptr[i] = vk;
             }
         }
@@ -139,6 +137,7 @@ typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
+template <typename R>
 __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
@@ -151,26 +150,27 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
     const int W = d.cols;
     const size_t HW = (size_t)d.rows * W;
     const DtJob job = p.jobs[j];
-    const float *src = p.resp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)job.filter * HW + (size_t)y * W;
-    const float *msg_row = p.msg + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + (size_t)y * W;
+    const R *src = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)job.filter * HW + (size_t)y * W;
+    const R *msg_row = static_cast<const R *>(p.msg) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + (size_t)y * W;
     const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y * W;
-    float *tmp = p.tmp + obase;
+    R *tmp = static_cast<R *>(p.tmp) + obase;
     int *ixr = p.IxRaw32 + obase;
-    __shared__ float ring_z[kDtT * 64], ring_s[kDtT * 64];
+    __shared__ R ring_z[kDtT * 64], ring_s[kDtT * 64];
     __shared__ int ring_v[kDtT * 64];
-    DtRing ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
-                reinterpret_cast<StkEntry *>(p.stk) +
-                    ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[blockIdx.x]) + threadIdx.x, 0};
+    DtRing<R> ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
+                   reinterpret_cast<StkEntryT<R> *>(p.stk) +
+                       ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[blockIdx.x]) + threadIdx.x, 0};
     const int *cs = p.child_slots;
     const int cb = job.child_begin, ce = job.child_end;
     const int N = active ? W : 0;
     if (N == 0) return;
-    auto load = [&](int q0, float *buf) {
-        if (q0 + kDtCH <= N) {
-            const v4f_u a0 = *reinterpret_cast<const v4f_u *>(src + q0), a1 = *reinterpret_cast<const v4f_u *>(src + q0 + 4);
+    auto load = [&](int q0, R *buf) {
+        if (sizeof(R) == 4 && q0 + kDtCH <= N) {
+            const float *srcf = reinterpret_cast<const float *>(src);
+            const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0), a1 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4);
             buf[0] = a0.x; buf[1] = a0.y; buf[2] = a0.z; buf[3] = a0.w; buf[4] = a1.x; buf[5] = a1.y; buf[6] = a1.z; buf[7] = a1.w;
             for (int c = cb; c < ce; ++c) {   // children's messages, descending child order
-                const float *m = msg_row + (size_t)cs[c] * HW + q0;
+                const float *m = reinterpret_cast<const float *>(msg_row + (size_t)cs[c] * HW) + q0;
                 const v4f_u m0 = *reinterpret_cast<const v4f_u *>(m), m1 = *reinterpret_cast<const v4f_u *>(m + 4);
                 buf[0] = buf[0] + m0.x; buf[1] = buf[1] + m0.y; buf[2] = buf[2] + m0.z; buf[3] = buf[3] + m0.w;
                 buf[4] = buf[4] + m1.x; buf[5] = buf[5] + m1.y; buf[6] = buf[6] + m1.z; buf[7] = buf[7] + m1.w;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
         } else {
 #pragma unroll
             for (int i = 0; i < kDtCH; ++i) {
-                float v = 0.f;
+                R v = (R)0;
                 if (q0 + i < N) {
                     v = src[q0 + i];
                     for (int c = cb; c < ce; ++c) v = v + msg_row[(size_t)cs[c] * HW + q0 + i];
@@ -187,10 +187,11 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
             }
         }
     };
-    auto store = [&](int q0, const float *out, const int *ptr) {
-        if (q0 + kDtCH <= N) {
-            *reinterpret_cast<v4f_u *>(tmp + q0) = v4f_u{out[0], out[1], out[2], out[3]};
-            *reinterpret_cast<v4f_u *>(tmp + q0 + 4) = v4f_u{out[4], out[5], out[6], out[7]};
+    auto store = [&](int q0, const R *out, const int *ptr) {
+        if (sizeof(R) == 4 && q0 + kDtCH <= N) {
+            float *tmpf = reinterpret_cast<float *>(tmp);
+            *reinterpret_cast<v4f_u *>(tmpf + q0) = v4f_u{(float)out[0], (float)out[1], (float)out[2], (float)out[3]};
+            *reinterpret_cast<v4f_u *>(tmpf + q0 + 4) = v4f_u{(float)out[4], (float)out[5], (float)out[6], (float)out[7]};
             *reinterpret_cast<v4i_u *>(ixr + q0) = v4i_u{ptr[0], ptr[1], ptr[2], ptr[3]};
             *reinterpret_cast<v4i_u *>(ixr + q0 + 4) = v4i_u{ptr[4], ptr[5], ptr[6], ptr[7]};
         } else {
@@ -199,17 +200,19 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
                 if (q0 + i < N) { tmp[q0 + i] = out[i]; ixr[q0 + i] = ptr[i]; }
         }
     };
-    dt_stream(N, job.ax, job.bx, job.osx, ring, load, store);
+    dt_stream<R>(N, job.ax, job.bx, job.osx, ring, load, store);
 }
 
-void launch_dt_rows(const DpParams &p, int nframes, hipStream_t s)
+void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.JG == 0 || p.nrows_flat == 0) return;
     dim3 grid((p.nrows_flat + 63) / 64, p.JG, nframes);
-    hipLaunchKernelGGL(k_dt_rows, grid, dim3(64), 0, s, p);
+    if (f64) hipLaunchKernelGGL(k_dt_rows<double>, grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(k_dt_rows<float>, grid, dim3(64), 0, s, p);
 }
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
+template <typename R>
 __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
 {
     const int cidx = blockIdx.x * 64 + threadIdx.x;
@@ -222,37 +225,39 @@ __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
     const size_t HW = (size_t)H * W;
     const DtJob job = p.jobs[j];
     const size_t base = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + x;
-    const float *tmp = p.tmp + base;
-    float *dt = p.dt + base;
+    const R *tmp = static_cast<const R *>(p.tmp) + base;
+    R *dt = static_cast<R *>(p.dt) + base;
     int16_t *iyr = p.IyRaw + base;
-    __shared__ float ring_z[kDtT * 64], ring_s[kDtT * 64];
+    __shared__ R ring_z[kDtT * 64], ring_s[kDtT * 64];
     __shared__ int ring_v[kDtT * 64];
-    DtRing ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
-                reinterpret_cast<StkEntry *>(p.stk) +
-                    ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[blockIdx.x]) + threadIdx.x, 0};
-    auto load = [&](int q0, float *buf) {
+    DtRing<R> ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
+                   reinterpret_cast<StkEntryT<R> *>(p.stk) +
+                       ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[blockIdx.x]) + threadIdx.x, 0};
+    auto load = [&](int q0, R *buf) {
 #pragma unroll
-        for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmp[(size_t)(q0 + i) * W] : 0.f;
+        for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmp[(size_t)(q0 + i) * W] : (R)0;
     };
-    auto store = [&](int q0, const float *out, const int *ptr) {
+    auto store = [&](int q0, const R *out, const int *ptr) {
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i)
             if (q0 + i < H) { dt[(size_t)(q0 + i) * W] = out[i]; iyr[(size_t)(q0 + i) * W] = (int16_t)ptr[i]; }
     };
-    dt_stream(H, job.ay, job.by, job.osy, ring, load, store);
+    dt_stream<R>(H, job.ay, job.by, job.osy, ring, load, store);
 }
 
-void launch_dt_cols(const DpParams &p, int nframes, hipStream_t s)
+void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.JG == 0 || p.ncols_flat == 0) return;
     dim3 grid((p.ncols_flat + 63) / 64, p.JG, nframes);
-    hipLaunchKernelGGL(k_dt_cols, grid, dim3(64), 0, s, p);
+    if (f64) hipLaunchKernelGGL(k_dt_cols<double>, grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(k_dt_cols<float>, grid, dim3(64), 0, s, p);
 }
 
 // ---- combine: thread = cell of one part (block.y), all parent mixtures -------------------------------
 // weighted[mm] = score_dt[mm] + bias(mm)[m]; reduceMax (strict >, first wins, start -inf; K==1 copies);
 // Ix/Iy picked from the winning mixture, with the reference's Iy composition
 // Iy[y][x] = IyRaw[y][Ix[y][x]] (include/DistanceTransform.hpp:233-244); message = max value.
+template <typename R>
 __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,28 +272,30 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
     const size_t HW = (size_t)d.rows * W;
     const int y = local / W;
     const size_t gbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)cj.job_begin * HW;
-    float dtv[kMaxMix];
+    const R *dtp = static_cast<const R *>(p.dt);
+    R dtv[kMaxMix];
     int ixv[kMaxMix];
 #pragma unroll
     for (int mm = 0; mm < kMaxMix; ++mm) {
-        dtv[mm] = 0.f; ixv[mm] = 0;
+        dtv[mm] = (R)0; ixv[mm] = 0;
         if (mm < cj.nmix) {
-            dtv[mm] = p.dt[gbase + (size_t)mm * HW + local];
+            dtv[mm] = dtp[gbase + (size_t)mm * HW + local];
             ixv[mm] = p.IxRaw32[gbase + (size_t)mm * HW + local];
         }
     }
     const size_t obase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + (size_t)cj.slot * HW + local;
+    R *msg = static_cast<R *>(p.msg);
     for (int pm = 0; pm < cj.npar; ++pm) {
-        float best;
+        R best;
         int bi = 0, ix = ixv[0];
         if (cj.nmix == 1) {
-            best = dtv[0] + p.biasw[cj.bias_off[0] + pm];
+            best = dtv[0] + (R)p.biasw[cj.bias_off[0] + pm];
         } else {
-            best = -INFINITY;
+            best = -RealLimits<R>::inf();
 #pragma unroll
             for (int mm = 0; mm < kMaxMix; ++mm) {
                 if (mm < cj.nmix) {
-                    const float wv = dtv[mm] + p.biasw[cj.bias_off[mm] + pm];
+                    const R wv = dtv[mm] + (R)p.biasw[cj.bias_off[mm] + pm];
                     if (wv > best) { bi = mm; best = wv; ix = ixv[mm]; }
                 }
             }
@@ -298,18 +305,20 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
         p.Ix[o] = (int16_t)ix;
         p.Iy[o] = (int16_t)iy;
         p.Ik[o] = (uint8_t)bi;
-        p.msg[o] = best;
+        msg[o] = best;
     }
 }
 
-void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, hipStream_t s)
+void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hipStream_t s)
 {
     if (ncjobs == 0 || p.cell_per_frame == 0) return;
     dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), ncjobs, nframes);
-    hipLaunchKernelGGL(k_dp_combine, grid, dim3(256), 0, s, p);
+    if (f64) hipLaunchKernelGGL(k_dp_combine<double>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_dp_combine<float>, grid, dim3(256), 0, s, p);
 }
 
 // ---- root: rootv = max over root mixtures of (accumulated score + bias) ----------------------------
+template <typename R>
 __global__ __launch_bounds__(256) void k_dp_root(DpParams p)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,39 +330,41 @@ __global__ __launch_bounds__(256) void k_dp_root(DpParams p)
     const LevelDesc d = p.lv[lo];
     const int local = (int)(idx - d.cell_off);
     const size_t HW = (size_t)d.rows * d.cols;
-    const float *resp = p.resp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
-    const float *msg_base = p.msg + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS;
-    float best;
+    const R *resp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
+    const R *msg_base = static_cast<const R *>(p.msg) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS;
+    R best;
     int bi = 0;
     if (rj.nmix == 1) {
-        float v = resp[(size_t)rj.filter[0] * HW + local];
+        R v = resp[(size_t)rj.filter[0] * HW + local];
         for (int k = rj.child_begin; k < rj.child_end; ++k) v = v + msg_base[(size_t)p.child_slots[k] * HW + local];
-        best = v + rj.bias;
+        best = v + (R)rj.bias;
     } else {
-        best = -INFINITY;
+        best = -RealLimits<R>::inf();
         for (int mm = 0; mm < rj.nmix; ++mm) {
-            float v = resp[(size_t)rj.filter[mm] * HW + local];
+            R v = resp[(size_t)rj.filter[mm] * HW + local];
             // message slot of child k towards root mixture mm = child_slots[k] + mm
             for (int k = rj.child_begin; k < rj.child_end; ++k)
                 v = v + msg_base[(size_t)(p.child_slots[k] + mm) * HW + local];
-            const float wv = v + rj.bias;
+            const R wv = v + (R)rj.bias;
             if (wv > best) { bi = mm; best = wv; }
         }
     }
     const size_t o = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NC + (size_t)c * HW + local;
-    p.rootv[o] = best;
+    static_cast<R *>(p.rootv)[o] = best;
     p.rooti[o] = bi;
 }
 
-void launch_dp_root(const DpParams &p, int nframes, hipStream_t s)
+void launch_dp_root(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.cell_per_frame == 0) return;
     dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), p.NC, nframes);
-    hipLaunchKernelGGL(k_dp_root, grid, dim3(256), 0, s, p);
+    if (f64) hipLaunchKernelGGL(k_dp_root<double>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_dp_root<float>, grid, dim3(256), 0, s, p);
 }
 
 // ---- argmin ------------------------------------------------------------------------------------
 // find: rootv > thresh (strict, src/DynamicProgram.cpp:208) -> append (frame, component, level, x, y, score, mix)
+template <typename R>
 __global__ __launch_bounds__(256) void k_argmin_find(ArgminParams p)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,31 +376,33 @@ __global__ __launch_bounds__(256) void k_argmin_find(ArgminParams p)
     const int local = (int)(idx - d.cell_off);
     const size_t HW = (size_t)d.rows * d.cols;
     const size_t o = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NC + (size_t)c * HW + local;
-    const float v = p.rootv[o];
-    if (!(v > p.thresh)) return;
+    const R v = static_cast<const R *>(p.rootv)[o];
+    if (!(v > (R)p.thresh)) return;
     const int slot = atomicAdd(p.count, 1);
     if (slot >= p.capacity) return;
     int32_t *rec = p.cand + (size_t)slot * p.stride;
     rec[0] = frame; rec[1] = c; rec[2] = lo;
     rec[3] = local % d.cols; rec[4] = local / d.cols;
-    rec[5] = __float_as_int(v);
+    rec[5] = __float_as_int((float)v);   // Candidate::confidence_ is float for every T (include/Candidate.hpp:72)
     rec[6] = 0;
     rec[7] = p.rooti[o];   // root mixture, consumed by the walk kernel
 }
 
-void launch_argmin_find(const ArgminParams &p, hipStream_t s)
+void launch_argmin_find(const ArgminParams &p, bool f64, hipStream_t s)
 {
     if (p.cell_per_frame == 0) return;
     dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), p.NC, p.nframes);
-    hipLaunchKernelGGL(k_argmin_find, grid, dim3(256), 0, s, p);
+    if (f64) hipLaunchKernelGGL(k_argmin_find<double>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_argmin_find<float>, grid, dim3(256), 0, s, p);
 }
 
-__device__ __forceinline__ int round_mul(int a, float s)
-{   // cv::Point_<int> * float -> saturate_cast<int>(a*s) = cvRound: round half to even
-    return __float2int_rn((float)a * s);
-}
+template <typename R> __device__ __forceinline__ int round_mul(int a, R s);
+// cv::Point_<int> * T -> saturate_cast<int>(a*s) = cvRound: round half to even
+template <> __device__ __forceinline__ int round_mul<float>(int a, float s) { return __float2int_rn((float)a * s); }
+template <> __device__ __forceinline__ int round_mul<double>(int a, double s) { return __double2int_rn((double)a * s); }
 
 // walk: one thread per candidate follows Ix/Iy/Ik from the root (src/DynamicProgram.cpp:218-244)
+template <typename R>
 __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
     const LevelDesc d = p.lv[l];
     const int W = d.cols;
     const size_t HW = (size_t)d.rows * W;
-    const float scale = p.scales[l];
+    const R scale = (R)p.scales[l];   // T scale = scales[n] (vectorf), src/DynamicProgram.cpp:199
     const PartWalk *walk = p.walk + p.walk_off[c];
     const int nparts = p.walk_off[c + 1] - p.walk_off[c];
     const size_t pbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS;
@@ -420,8 +433,8 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
         }
         xv[pidx] = x; yv[pidx] = y; mv[pidx] = m;
         const int ks = walk[pidx].ksize[m];
-        const int x1 = round_mul(x - 1, scale), y1 = round_mul(y - 1, scale);
-        const int x2 = x1 + round_mul(ks, scale) - 1, y2 = y1 + round_mul(ks, scale) - 1;
+        const int x1 = round_mul<R>(x - 1, scale), y1 = round_mul<R>(y - 1, scale);
+        const int x2 = x1 + round_mul<R>(ks, scale) - 1, y2 = y1 + round_mul<R>(ks, scale) - 1;
         const int rx = min(x1, x2), ry = min(y1, y2);
         rects[pidx * 4 + 0] = rx;
         rects[pidx * 4 + 1] = ry;
@@ -432,10 +445,11 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
     rec[7] = 0;
 }
 
-void launch_argmin_walk(const ArgminParams &p, int ncand, hipStream_t s)
+void launch_argmin_walk(const ArgminParams &p, int ncand, bool f64, hipStream_t s)
 {
     if (ncand == 0) return;
-    hipLaunchKernelGGL(k_argmin_walk, dim3((ncand + 63) / 64), dim3(64), 0, s, p, ncand);
+    if (f64) hipLaunchKernelGGL(k_argmin_walk<double>, dim3((ncand + 63) / 64), dim3(64), 0, s, p, ncand);
+    else hipLaunchKernelGGL(k_argmin_walk<float>, dim3((ncand + 63) / 64), dim3(64), 0, s, p, ncand);
 }
 
 }  // namespace pbd

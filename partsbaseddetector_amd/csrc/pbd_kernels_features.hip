@@ -107,12 +107,17 @@ void launch_pyrdown_range(const PyrParams &p, int nframes, int first_level, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// HOG cell histograms, gather form.  One thread per block (cell of the `blocks` grid): it walks the
-// source pixels that the reference's scatter loop (src/HOGFeatures.cpp:202-267) adds into this
-// block, in the same raster order, so every bin sees the same sequence of float additions.
-// Bins are 18 registers; the selected bin is updated through predicated adds of +0.0f, which leave
-// a non-negative sum unchanged.  Also writes the block energy (:270-283).
+// HOG cell histograms, gather form (R = reference template parameter T).  One thread per block (cell of
+// the `blocks` grid): it walks the source pixels that the reference's scatter loop
+// (src/HOGFeatures.cpp:202-267) adds into this block, in the same raster order, so every bin sees the
+// same sequence of additions.  Bins are 18 registers; the selected bin is updated through predicated
+// adds of +0, which leave a non-negative sum unchanged.  Also writes the block energy (:270-283).
 // ------------------------------------------------------------------------------------------------
+template <typename R> __device__ __forceinline__ R real_sqrt(R v);
+template <> __device__ __forceinline__ float real_sqrt<float>(float v) { return sqrtf(v); }
+template <> __device__ __forceinline__ double real_sqrt<double>(double v) { return sqrt(v); }
+
+template <typename R>
 __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,13 +132,14 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
     const int vish = d.blk_rows * sbin, visw = d.blk_cols * sbin;
     const uint8_t *im = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off) * cn;
     const size_t stride = (size_t)cols * cn;
+    const HogCoordT<R> *coord = static_cast<const HogCoordT<R> *>(p.coord);
 
-    const float uu[9] = {1.000f, 0.9397f, 0.7660f, 0.5000f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
-    const float vv[9] = {0.000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
+    const R uu[9] = {(R)1.000, (R)0.9397, (R)0.7660, (R)0.5000, (R)0.1736, (R)-0.1736, (R)-0.5000, (R)-0.7660, (R)-0.9397};
+    const R vv[9] = {(R)0.000, (R)0.3420, (R)0.6428, (R)0.8660, (R)0.9848, (R)0.9848, (R)0.8660, (R)0.6428, (R)0.3420};
 
-    float h[18];
+    R h[18];
 #pragma unroll
-    for (int o = 0; o < 18; ++o) h[o] = 0.0f;
+    for (int o = 0; o < 18; ++o) h[o] = (R)0;
 
     int ylo = sbin * by - sbin, yhi = sbin * by + 2 * sbin;
     int xlo = sbin * bx - sbin, xhi = sbin * bx + 2 * sbin;
@@ -143,82 +149,85 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
     if (xhi > visw - 1) xhi = visw - 1;
 
     for (int y = ylo; y < yhi; ++y) {
-        const HogCoord cy = p.coord[y];
-        float wy;
+        const HogCoordT<R> cy = coord[y];
+        R wy;
         if (cy.ip == by) wy = cy.v1;            // this block is (iyp, .): weight vy1
         else if (cy.ip + 1 == by) wy = cy.v0;   // this block is (iyp+1, .): weight vy0
         else continue;
         const int ys = y < rows - 2 ? y : rows - 2;
         for (int x = xlo; x < xhi; ++x) {
-            const HogCoord cx = p.coord[x];
-            float wx;
+            const HogCoordT<R> cx = coord[x];
+            R wx;
             if (cx.ip == bx) wx = cx.v1;
             else if (cx.ip + 1 == bx) wx = cx.v0;
             else continue;
             const int xs = x < cols - 2 ? x : cols - 2;
-            float dx, dy, v;
+            R dx, dy, v;
             if (cn == 1) {
                 const uint8_t *s = im + xs + (size_t)ys * stride;
-                dy = (float)((int)s[stride] - (int)*(s - stride));
-                dx = (float)((int)s[1] - (int)s[-1]);
+                dy = (R)((int)s[stride] - (int)*(s - stride));
+                dx = (R)((int)s[1] - (int)s[-1]);
                 v = dx * dx + dy * dy;
             } else {
                 const uint8_t *s = im + 3 * xs + (size_t)ys * stride;
-                const float dyb = (float)((int)s[stride] - (int)*(s - stride));
-                const float dxb = (float)((int)s[3] - (int)s[-3]);
-                const float vb = dxb * dxb + dyb * dyb;
-                const float dyg = (float)((int)s[stride + 1] - (int)*(s - stride + 1));
-                const float dxg = (float)((int)s[4] - (int)s[-2]);
-                const float vg = dxg * dxg + dyg * dyg;
-                dy = (float)((int)s[stride + 2] - (int)*(s - stride + 2));
-                dx = (float)((int)s[5] - (int)s[-1]);
+                const R dyb = (R)((int)s[stride] - (int)*(s - stride));
+                const R dxb = (R)((int)s[3] - (int)s[-3]);
+                const R vb = dxb * dxb + dyb * dyb;
+                const R dyg = (R)((int)s[stride + 1] - (int)*(s - stride + 1));
+                const R dxg = (R)((int)s[4] - (int)s[-2]);
+                const R vg = dxg * dxg + dyg * dyg;
+                dy = (R)((int)s[stride + 2] - (int)*(s - stride + 2));
+                dx = (R)((int)s[5] - (int)s[-1]);
                 v = dx * dx + dy * dy;
                 if (vg > v) { v = vg; dx = dxg; dy = dyg; }
                 if (vb > v) { v = vb; dx = dxb; dy = dyb; }
             }
-            float best_dot = 0.0f;
+            R best_dot = (R)0;
             int best_o = 0;
 #pragma unroll
             for (int o = 0; o < 9; ++o) {
-                const float dot = uu[o] * dx + vv[o] * dy;
+                const R dot = uu[o] * dx + vv[o] * dy;
                 if (dot > best_dot) { best_dot = dot; best_o = o; }
                 else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
             }
-            v = sqrtf(v);
-            // the four scatter lines multiply (vy?*vx?) first, then by v; float products commute
-            const float contrib = (wy * wx) * v;
+            v = real_sqrt<R>(v);
+            // the four scatter lines multiply (vy?*vx?) first, then by v; products commute
+            const R contrib = (wy * wx) * v;
 #pragma unroll
-            for (int o = 0; o < 18; ++o) h[o] += (o == best_o) ? contrib : 0.0f;
+            for (int o = 0; o < 18; ++o) h[o] += (o == best_o) ? contrib : (R)0;
         }
     }
-    float *hist = p.hist + (size_t)frame * 18 * p.blk_per_frame + idx;
+    R *hist = static_cast<R *>(p.hist) + (size_t)frame * 18 * p.blk_per_frame + idx;
 #pragma unroll
     for (int o = 0; o < 18; ++o) hist[(size_t)o * p.blk_per_frame] = h[o];
-    float e = 0.0f;
+    R e = (R)0;
 #pragma unroll
     for (int o = 0; o < 9; ++o) {
-        const float t = h[o] + h[o + 9];
+        const R t = h[o] + h[o + 9];
         e += t * t;
     }
-    p.norm[(size_t)frame * p.blk_per_frame + idx] = e;
+    static_cast<R *>(p.norm)[(size_t)frame * p.blk_per_frame + idx] = e;
 }
 
-void launch_hog_hist(const HogParams &p, int nframes, hipStream_t s)
+void launch_hog_hist(const HogParams &p, int nframes, bool f64, hipStream_t s)
 {
     dim3 grid((unsigned)((p.blk_per_frame + 255) / 256), nframes);
-    hipLaunchKernelGGL(k_hog_hist, grid, dim3(256), 0, s, p);
+    if (f64) hipLaunchKernelGGL(k_hog_hist<double>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_hog_hist<float>, grid, dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Normalisation and the 32 output channels per interior cell (src/HOGFeatures.cpp:286-340).
 // One thread per cell.  The four normalisers are evaluated in double as the reference does.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float hog_norm(const float *n, int stride)
+template <typename R>
+__device__ __forceinline__ R hog_norm(const R *n, int stride)
 {
-    const float s4 = ((n[0] + n[1]) + n[stride]) + n[stride + 1];
-    return (float)(1.0 / sqrt((double)s4 + 0.0001));
+    const R s4 = ((n[0] + n[1]) + n[stride]) + n[stride + 1];
+    return (R)(1.0 / sqrt((double)s4 + 0.0001));
 }
 
+template <typename R>
 __global__ __launch_bounds__(256) void k_hog_feat(HogParams p)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,52 +238,55 @@ __global__ __launch_bounds__(256) void k_hog_feat(HogParams p)
     const int local = (int)(idx - d.cell_off);
     const int y = local / d.cols, x = local - y * d.cols;
     const int bw = d.blk_cols;
-    const float *norm = p.norm + (size_t)frame * p.blk_per_frame + d.blk_off;
-    const float n1 = hog_norm(norm + (size_t)(y + 1) * bw + (x + 1), bw);
-    const float n2 = hog_norm(norm + (size_t)y * bw + (x + 1), bw);
-    const float n3 = hog_norm(norm + (size_t)(y + 1) * bw + x, bw);
-    const float n4 = hog_norm(norm + (size_t)y * bw + x, bw);
-    const float *hist = p.hist + (size_t)frame * 18 * p.blk_per_frame + d.blk_off + (size_t)(y + 1) * bw + (x + 1);
-    float hv[18];
+    const R *norm = static_cast<const R *>(p.norm) + (size_t)frame * p.blk_per_frame + d.blk_off;
+    const R n1 = hog_norm<R>(norm + (size_t)(y + 1) * bw + (x + 1), bw);
+    const R n2 = hog_norm<R>(norm + (size_t)y * bw + (x + 1), bw);
+    const R n3 = hog_norm<R>(norm + (size_t)(y + 1) * bw + x, bw);
+    const R n4 = hog_norm<R>(norm + (size_t)y * bw + x, bw);
+    const R *hist = static_cast<const R *>(p.hist) + (size_t)frame * 18 * p.blk_per_frame + d.blk_off + (size_t)(y + 1) * bw + (x + 1);
+    R hv[18];
 #pragma unroll
     for (int o = 0; o < 18; ++o) hv[o] = hist[(size_t)o * p.blk_per_frame];
 
-    float out[32];
-    float t1 = 0.0f, t2 = 0.0f, t3 = 0.0f, t4 = 0.0f;
+    const R lim = (R)0.2;
+    R out[32];
+    R t1 = (R)0, t2 = (R)0, t3 = (R)0, t4 = (R)0;
 #pragma unroll
     for (int o = 0; o < 18; ++o) {
-        const float val = hv[o];
-        float h1 = val * n1; h1 = 0.2f < h1 ? 0.2f : h1;
-        float h2 = val * n2; h2 = 0.2f < h2 ? 0.2f : h2;
-        float h3 = val * n3; h3 = 0.2f < h3 ? 0.2f : h3;
-        float h4 = val * n4; h4 = 0.2f < h4 ? 0.2f : h4;
-        out[o] = (float)(0.5 * (double)(((h1 + h2) + h3) + h4));
+        const R val = hv[o];
+        R h1 = val * n1; h1 = lim < h1 ? lim : h1;
+        R h2 = val * n2; h2 = lim < h2 ? lim : h2;
+        R h3 = val * n3; h3 = lim < h3 ? lim : h3;
+        R h4 = val * n4; h4 = lim < h4 ? lim : h4;
+        out[o] = (R)(0.5 * (double)(((h1 + h2) + h3) + h4));
         t1 += h1; t2 += h2; t3 += h3; t4 += h4;
     }
 #pragma unroll
     for (int o = 0; o < 9; ++o) {
-        const float sum = hv[o] + hv[o + 9];
-        float h1 = sum * n1; h1 = 0.2f < h1 ? 0.2f : h1;
-        float h2 = sum * n2; h2 = 0.2f < h2 ? 0.2f : h2;
-        float h3 = sum * n3; h3 = 0.2f < h3 ? 0.2f : h3;
-        float h4 = sum * n4; h4 = 0.2f < h4 ? 0.2f : h4;
-        out[18 + o] = (float)(0.5 * (double)(((h1 + h2) + h3) + h4));
+        const R sum = hv[o] + hv[o + 9];
+        R h1 = sum * n1; h1 = lim < h1 ? lim : h1;
+        R h2 = sum * n2; h2 = lim < h2 ? lim : h2;
+        R h3 = sum * n3; h3 = lim < h3 ? lim : h3;
+        R h4 = sum * n4; h4 = lim < h4 ? lim : h4;
+        out[18 + o] = (R)(0.5 * (double)(((h1 + h2) + h3) + h4));
     }
-    out[27] = (float)(0.2357 * (double)t1);
-    out[28] = (float)(0.2357 * (double)t2);
-    out[29] = (float)(0.2357 * (double)t3);
-    out[30] = (float)(0.2357 * (double)t4);
-    out[31] = 0.0f;
-    float4 *dst = reinterpret_cast<float4 *>(p.feat + ((size_t)frame * p.cell_per_frame + idx) * 32);
+    out[27] = (R)(0.2357 * (double)t1);
+    out[28] = (R)(0.2357 * (double)t2);
+    out[29] = (R)(0.2357 * (double)t3);
+    out[30] = (R)(0.2357 * (double)t4);
+    out[31] = (R)0;
+    R *dst = static_cast<R *>(p.feat) + ((size_t)frame * p.cell_per_frame + idx) * 32;
+    typedef R rv4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+    for (int i = 0; i < 8; ++i) reinterpret_cast<rv4 *>(dst)[i] = rv4{out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]};
 }
 
-void launch_hog_feat(const HogParams &p, int nframes, hipStream_t s)
+void launch_hog_feat(const HogParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.cell_per_frame == 0) return;
     dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), nframes);
-    hipLaunchKernelGGL(k_hog_feat, grid, dim3(256), 0, s, p);
+    if (f64) hipLaunchKernelGGL(k_hog_feat<double>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_hog_feat<float>, grid, dim3(256), 0, s, p);
 }
 
 }  // namespace pbd

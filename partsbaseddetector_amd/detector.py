@@ -56,6 +56,7 @@ class Handle:
         if rc != _lib.PBD_OK:
             raise PbdError(rc, self.lib.pbd_last_error(None).decode())
         self.h = h
+        self.dtype = np.float32 if real_type == _lib.REAL_F32 else np.float64   # reference template parameter T
         self.max_batch = max_batch
         self.max_candidates = max_candidates
         self.stride = self.lib.pbd_candidate_stride(self.h)
@@ -114,11 +115,11 @@ class Handle:
         planes = {_lib.STAGE_FEATURES: None, _lib.STAGE_RESPONSES: self.flat.nfilters,
                   _lib.STAGE_ROOTV: self.flat.ncomponents, _lib.STAGE_ROOTI: self.flat.ncomponents}[stage]
         if stage == _lib.STAGE_FEATURES:
-            dst = np.empty((rows, cols * self.flat.flen), np.float32)
+            dst = np.empty((rows, cols * self.flat.flen), self.dtype)
         elif stage == _lib.STAGE_ROOTI:
             dst = np.empty((planes, rows, cols), np.int32)
         else:
-            dst = np.empty((planes, rows, cols), np.float32)
+            dst = np.empty((planes, rows, cols), self.dtype)
         self.check(self.lib.pbd_get_stage(self.h, stage, frame, level, dst.ctypes.data, dst.nbytes))
         return dst
 
@@ -140,7 +141,7 @@ class HOGFeatures:
         return self._scales
 
     def pyramid(self, im: np.ndarray) -> List[np.ndarray]:
-        """pyramid(im, pyrafeatures): list of (H, W*flen) float32 maps, fine to coarse."""
+        """pyramid(im, pyrafeatures): list of (H, W*flen) maps of T, fine to coarse."""
         if im.dtype != np.uint8:
             # src/HOGFeatures.cpp:136-146 accepts 8U/16U/32F/64F; only 8-bit is built here
             raise PbdError(-2, f"image dtype {im.dtype}: only uint8 is supported")
@@ -150,7 +151,7 @@ class HOGFeatures:
         if not im.flags.c_contiguous and not (im.strides[2] == 1 and im.strides[1] == cn):
             im = np.ascontiguousarray(im)
         plan = self.hd.plan(rows, cols)
-        feats = [np.empty((int(r), int(c) * self.hd.flat.flen), np.float32)
+        feats = [np.empty((int(r), int(c) * self.hd.flat.flen), self.hd.dtype)
                  for r, c in zip(plan["feat_rows"], plan["feat_cols"])]
         arr = _lib.ptr_array(feats)
         self.hd.check(self.hd.lib.pbd_features_pyramid(self.hd.h, im.ctypes.data, rows, cols, cn, im.strides[0], 0, arr))
@@ -175,7 +176,7 @@ class SpatialConvolutionEngine:
         self.hd = handle
 
     def setFilters(self, filters: Sequence[np.ndarray]) -> None:
-        fl = [np.ascontiguousarray(f, np.float32) for f in filters]
+        fl = [np.ascontiguousarray(f, self.hd.dtype) for f in filters]
         ks = np.array([f.shape[0] for f in fl], np.int32)
         arr = _lib.ptr_array(fl)
         self.hd.check(self.hd.lib.pbd_conv_set_filters(self.hd.h, len(fl), arr, _lib.ptr(ks, C.c_int)))
@@ -184,11 +185,11 @@ class SpatialConvolutionEngine:
     def pdf(self, features: Sequence[np.ndarray]) -> List[np.ndarray]:
         """pdf(features, responses): responses[level] is (nfilters, H, W); responses[level][filter] as in the reference."""
         flen = self.hd.flat.flen
-        feats = [np.ascontiguousarray(f, np.float32) for f in features]
+        feats = [np.ascontiguousarray(f, self.hd.dtype) for f in features]
         rows = np.array([f.shape[0] for f in feats], np.int32)
         cols = np.array([f.shape[1] // flen for f in feats], np.int32)
         nf = getattr(self, "_nfilters", self.hd.flat.nfilters)
-        resp = [np.empty((nf, int(r), int(c)), np.float32) for r, c in zip(rows, cols)]
+        resp = [np.empty((nf, int(r), int(c)), self.hd.dtype) for r, c in zip(rows, cols)]
         self.hd.check(self.hd.lib.pbd_conv_pdf(self.hd.h, len(feats), _lib.ptr_array(feats), _lib.ptr(rows, C.c_int),
                                                _lib.ptr(cols, C.c_int), _lib.ptr_array(resp)))
         return resp
@@ -204,14 +205,14 @@ class DynamicProgram:
         """min(parts, scores, Ix, Iy, Ik, rootv, rooti); scores[level] is (nfilters, H, W).
         Returns per level: Ix, Iy, Ik as (nslots, H, W) int32 (slot = pbd_ptr_slot(c, part) + parent mixture),
         rootv (ncomponents, H, W) float32, rooti (ncomponents, H, W) int32."""
-        sc = [np.ascontiguousarray(s, np.float32) for s in scores]
+        sc = [np.ascontiguousarray(s, self.hd.dtype) for s in scores]
         rows = np.array([s.shape[1] for s in sc], np.int32)
         cols = np.array([s.shape[2] for s in sc], np.int32)
         ns, nc = max(self.hd.flat.nslots, 1), self.hd.flat.ncomponents
         Ix = [np.zeros((ns, int(r), int(c)), np.int32) for r, c in zip(rows, cols)]
         Iy = [np.zeros((ns, int(r), int(c)), np.int32) for r, c in zip(rows, cols)]
         Ik = [np.zeros((ns, int(r), int(c)), np.int32) for r, c in zip(rows, cols)]
-        rootv = [np.empty((nc, int(r), int(c)), np.float32) for r, c in zip(rows, cols)]
+        rootv = [np.empty((nc, int(r), int(c)), self.hd.dtype) for r, c in zip(rows, cols)]
         rooti = [np.empty((nc, int(r), int(c)), np.int32) for r, c in zip(rows, cols)]
         self.hd.check(self.hd.lib.pbd_dp_min(self.hd.h, len(sc), _lib.ptr(rows, C.c_int), _lib.ptr(cols, C.c_int),
                                              _lib.ptr_array(sc), _lib.ptr_array(Ix), _lib.ptr_array(Iy),
@@ -232,9 +233,10 @@ class PartsBasedDetector:
     """PartsBasedDetector<float> (include/PartsBasedDetector.hpp:152-175)."""
 
     def __init__(self, device: int = 0, conv_mode: int = _lib.CONV_EXACT, max_batch: int = 1,
-                 max_candidates: int = 1 << 18, stream: Optional[int] = None):
+                 max_candidates: int = 1 << 18, stream: Optional[int] = None, dtype=np.float32):
+        """dtype: the reference's template parameter T (float32 as src/demo.cpp:85, float64 as the ECTO/ROS callers)."""
         self._kw = dict(device=device, conv_mode=conv_mode, max_batch=max_batch, max_candidates=max_candidates,
-                        stream=stream)
+                        stream=stream, real_type=_lib.REAL_F32 if np.dtype(dtype) == np.float32 else _lib.REAL_F64)
         self.hd: Optional[Handle] = None
         self._name = ""
 

@@ -57,7 +57,7 @@ def test_unsupported_real_type_is_reported(lib):
     from partsbaseddetector_amd import _lib, model as M
     flat = M.synthetic_tiny_model().flatten()
     cm = _lib.c_model(flat)
-    cfg = _lib.CConfig(0, _lib.REAL_F64, _lib.CONV_EXACT, 1, 1024, None)
+    cfg = _lib.CConfig(0, 7, _lib.CONV_EXACT, 1, 1024, None)
     h = C.c_void_p()
     assert lib.pbd_create(C.byref(cm), C.byref(cfg), C.byref(h)) == -2
 

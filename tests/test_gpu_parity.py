@@ -224,3 +224,81 @@ def test_errors(det_mod):
         det.detect(synth.synthetic_frame(1, 100, 100), capacity=1)   # capacity overflow is reported
     assert e.value.code == -4
     det.hd.close()
+
+
+@pytest.mark.parametrize("shape,seed", [((480, 640), 1), ((1080, 1920), 2)])
+def test_person_model_full_size_frames(det_mod, oracle, shape, seed):
+    """BASELINE configs[1]/[3] sizes: one 640x480 and one 1920x1080 frame, whole path, vs the oracle."""
+    model = M.synthetic_person_model(thresh=18.9 if shape[0] == 480 else 19.3)
+    flat = model.flatten()
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    im = synth.synthetic_frame(seed, shape[0], shape[1], 3)
+    got = det.detect(im)
+    want = oracle.detect(flat, im)
+    assert len(want) > 0
+    _compare_candidates(got, want)
+    det.hd.close()
+
+
+def test_face_config_plumbing(det_mod, oracle):
+    """BASELINE configs[0]: face-like model (many parts, 1 mixture, several components sharing filters),
+    320x240 frame, interval 5."""
+    model = M.synthetic_face_model(thresh=6.0, nparts=20, ncomponents=3, interval=5)
+    flat = model.flatten()
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    im = synth.synthetic_frame(7, 240, 320, 3)
+    _compare_candidates(det.detect(im), oracle.detect(flat, im))
+    assert det.features_.nscales() == 18       # SURVEY.md Appendix B: 320x240, sbin 4, interval 5
+    det.hd.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# T = double (the reference's ECTO / ROS instantiation, cells/detect.cpp:93, ros/Node.hpp:121)
+# ---------------------------------------------------------------------------------------------------
+def _eq64(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_f64_features_conv_dp(det_mod, oracle):
+    from partsbaseddetector_amd import _lib
+    model = M.synthetic_tiny_model(linear_def=True)
+    flat = model.flatten()
+    hd = det_mod.Handle(flat, device=0, real_type=_lib.REAL_F64)
+    feats_eng = det_mod.HOGFeatures(hd)
+    for shape, cn in (((123, 157), 3), ((97, 131), 1)):
+        im = synth.synthetic_frame(11, shape[0], shape[1], cn)
+        got = feats_eng.pyramid(im)
+        want, scales = oracle.features_pyramid(flat, im, dtype=np.float64)
+        assert np.array_equal(feats_eng.scales(), scales)
+        for l, (a, b) in enumerate(zip(got, want)):
+            assert a.dtype == np.float64 and _eq64(a, b), (l, np.abs(a - b).max())
+    conv = det_mod.SpatialConvolutionEngine(hd)
+    rng = np.random.default_rng(5)
+    dims = [(37, 45), (3, 2), (12, 70)]
+    feats = [rng.random((h, w * 32)) * 0.4 for h, w in dims]
+    got = conv.pdf(feats)
+    for f, g in zip(feats, got):
+        assert _eq64(g, oracle.responses(flat, f))
+    dp = det_mod.DynamicProgram(hd)
+    scores = [rng.standard_normal((flat.nfilters, h, w)) for h, w in [(21, 30), (9, 7), (1, 6)]]
+    Ix, Iy, Ik, rootv, rooti = dp.min(scores)
+    for l, s in enumerate(scores):
+        oIx, oIy, oIk, orv, ori = oracle.dp_min(flat, 0, s)
+        assert _eq64(rootv[l][0], orv) and np.array_equal(rooti[l][0], ori)
+        assert np.array_equal(Ix[l], oIx) and np.array_equal(Iy[l], oIy) and np.array_equal(Ik[l], oIk)
+    hd.close()
+
+
+@pytest.mark.parametrize("which,shape,thresh", [("tiny", (96, 128), 0.6), ("person", (160, 120), 17.9), ("person", (480, 640), 18.9)])
+def test_f64_detect_end_to_end(det_mod, oracle, which, shape, thresh):
+    model = M.synthetic_tiny_model(thresh=thresh) if which == "tiny" else M.synthetic_person_model(thresh=thresh)
+    det = det_mod.PartsBasedDetector(device=0, dtype=np.float64)
+    det.distributeModel(model)
+    im = synth.synthetic_frame(21, shape[0], shape[1], 3)
+    got = det.detect(im)
+    want = oracle.detect(model.flatten(), im, dtype=np.float64)
+    assert len(want) > 0
+    _compare_candidates(got, want)
+    det.hd.close()
