@@ -41,6 +41,42 @@ class Candidate:
     def sort(candidates: List["Candidate"]) -> None:  # Candidate.hpp:91-99 (descending by score)
         candidates.sort(key=lambda c: -c.score())
 
+    def boundingBox(self):
+        """Candidate.hpp:105-111: hull of the part rectangles (cv::Rect operator|), as (x, y, w, h)."""
+        x, y, w, h = (int(v) for v in self.parts[0])
+        for r in self.parts:
+            bx, by, bw, bh = (int(v) for v in r)
+            if w <= 0 or h <= 0:            # a.empty(): a = b
+                x, y, w, h = bx, by, bw, bh
+            elif bw > 0 and bh > 0:
+                x1, y1 = min(x, bx), min(y, by)
+                w, h = max(x + w, bx + bw) - x1, max(y + h, by + bh) - y1
+                x, y = x1, y1
+        return x, y, w, h
+
+    @staticmethod
+    def nonMaximaSuppression(im_shape, candidates: List["Candidate"], overlap: float = 0.0) -> None:
+        """Candidate.hpp:277-304: greedy paint-the-canvas suppression on the bounding boxes, in the given
+        order (callers sort by score first: cells/detect.cpp:237-238, ros/Node.cpp:192-196).  In place."""
+        rows, cols = int(im_shape[0]), int(im_shape[1])
+        scratch = np.zeros((rows, cols), np.uint8)
+        keep = 0
+        for cand in list(candidates):
+            x, y, w, h = cand.boundingBox()
+            x1, y1 = max(x, 0), max(y, 0)                         # box & bounds (cv::Rect operator&)
+            x2, y2 = min(x + w, cols), min(y + h, rows)
+            if x2 - x1 <= 0 or y2 - y1 <= 0:
+                x1 = y1 = x2 = y2 = 0
+            area = (x2 - x1) * (y2 - y1)
+            boxsum = float(scratch[y1:y2, x1:x2].sum())
+            ratio = boxsum / area if area else float("nan")       # NaN > overlap is false: an empty box is kept
+            if ratio > overlap:
+                continue
+            scratch[y1:y2, x1:x2] = 1
+            candidates[keep] = cand
+            keep += 1
+        del candidates[keep:]
+
 
 class Handle:
     """Owns a pbd_handle (one handle = one host thread = one GPU)."""
