@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
-    ap.add_argument("--conv-mode", choices=["exact", "fma"], default="exact")
+    ap.add_argument("--conv-mode", choices=["exact", "fma", "mfma"], default="exact")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the same workload timed on the host CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
@@ -68,7 +68,7 @@ def main():
     flat = model.flatten()
     B, rows, cols, cn = args.batch, args.rows, args.cols, 3
     cap = 1 << 16
-    det = PartsBasedDetector(device=local_rank, conv_mode=_lib.CONV_EXACT if args.conv_mode == "exact" else _lib.CONV_FMA,
+    det = PartsBasedDetector(device=local_rank, conv_mode={"exact": _lib.CONV_EXACT, "fma": _lib.CONV_FMA, "mfma": _lib.CONV_MFMA}[args.conv_mode],
                              max_batch=B, max_candidates=cap)
     det.distributeModel(model)
     stride = det.hd.stride

@@ -185,6 +185,7 @@ struct pbd_handle {
 
     // device model tables
     DevBuf d_wts;                    // real-typed weights
+    DevBuf d_wrec;                   // bf16 hi/lo weight records of the matrix-core path
     DevTable<float> d_biasw;
     DevTable<int> d_child_slots, d_walk_off;
     DevTable<RootJob> d_rjobs;
@@ -438,6 +439,33 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
     }
     HIPCHK(h, h->d_wts.ensure(w.size() * sizeof(R)));
     HIPCHK(h, hipMemcpy(h->d_wts.p, w.data(), w.size() * sizeof(R), hipMemcpyHostToDevice));
+    if (h->cfg.conv_mode == PBD_CONV_MFMA) {
+        if (!fast) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA needs 5x5 filters and PBD_REAL_F32");
+        // records [pass][tap][160 filters][hi 32 bf16 | lo 32 bf16 | 8 pad], x = hi + lo with round-to-nearest-even
+        auto f2bf = [](float f) -> uint16_t {
+            uint32_t u; memcpy(&u, &f, 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto bf2f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+        const int passes = (nfilters + kMfmaFilterBlock - 1) / kMfmaFilterBlock;
+        std::vector<uint16_t> rec((size_t)passes * K * K * kMfmaFilterBlock * (kMfmaRecBytes / 2), 0);
+        for (int f = 0; f < nfilters; ++f) {
+            const float *src = reinterpret_cast<const float *>(filters[f]);
+            for (int t = 0; t < K * K; ++t) {
+                uint16_t *r = &rec[(((size_t)(f / kMfmaFilterBlock) * K * K + t) * kMfmaFilterBlock + f % kMfmaFilterBlock) * (kMfmaRecBytes / 2)];
+                for (int c = 0; c < 32; ++c) {
+                    const float v = src[(size_t)t * 32 + c];
+                    const uint16_t hi = f2bf(v);
+                    r[c] = hi;
+                    r[32 + c] = f2bf(v - bf2f(hi));
+                }
+            }
+        }
+        HIPCHK(h, h->d_wrec.ensure(rec.size() * 2));
+        HIPCHK(h, hipMemcpy(h->d_wrec.p, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
+    }
     h->F = nfilters; h->Fpad = Fpad; h->ksize = K;
     h->filter_ksize.assign(ksize, ksize + nfilters);
     h->filters_set = true;
@@ -670,7 +698,8 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     cp.feat = h->feat.p; cp.wts = h->d_wts.p; cp.resp = h->resp.p;
     cp.fma = h->cfg.conv_mode == PBD_CONV_FMA;
     ProfScope ps(h, PBD_K_CONV, st);
-    launch_conv(cp, nb, h->f64, st);
+    if (h->cfg.conv_mode == PBD_CONV_MFMA) launch_conv_mfma(cp, h->d_wrec.p, nb, st);
+    else launch_conv(cp, nb, h->f64, st);
 }
 
 // frames per DP chunk so that the chunk scratch stays within the budget
@@ -950,7 +979,7 @@ void pbd_destroy(pbd_handle *h)
                       &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();
-    h->d_wts.release(); h->d_biasw.release(); h->d_coord.release(); h->d_child_slots.release(); h->d_walk_off.release();
+    h->d_wts.release(); h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_child_slots.release(); h->d_walk_off.release();
     h->d_rjobs.release(); h->d_walk.release();
     for (auto &g : h->groups) { g.d_jobs.release(); g.d_cjobs.release(); }
     h->plans.clear();

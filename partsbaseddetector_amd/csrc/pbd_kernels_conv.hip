@@ -111,12 +111,19 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p
                 for (int pp = 0; pp < P; ++pp)
 #pragma unroll
                     for (int j = 0; j < K; ++j) fw[pp][j] = sp[(pp + i) * PW + j];
+                v4f wa[K], wb[K];
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
-                    const v4f wa = *reinterpret_cast<const v4f *>(wcur + (i * K + j) * Q);
-                    const v4f wb = *reinterpret_cast<const v4f *>(wcur + (i * K + j) * Q + 4);
-                    const v2f w[Q / 2] = {__builtin_shufflevector(wa, wa, 0, 1), __builtin_shufflevector(wa, wa, 2, 3),
-                                          __builtin_shufflevector(wb, wb, 0, 1), __builtin_shufflevector(wb, wb, 2, 3)};
+                    wa[j] = *reinterpret_cast<const v4f *>(wcur + (i * K + j) * Q);
+                    wb[j] = *reinterpret_cast<const v4f *>(wcur + (i * K + j) * Q + 4);
+                }
+                // every LDS read of this tap row is issued before the first multiply (counted lgkmcnt waits
+                // then retire them in order while the VALU works)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const v2f w[Q / 2] = {__builtin_shufflevector(wa[j], wa[j], 0, 1), __builtin_shufflevector(wa[j], wa[j], 2, 3),
+                                          __builtin_shufflevector(wb[j], wb[j], 0, 1), __builtin_shufflevector(wb[j], wb[j], 2, 3)};
 #pragma unroll
                     for (int pp = 0; pp < P; ++pp) {
                         const v2f f = v2f{fw[pp][j], fw[pp][j]};

@@ -83,11 +83,11 @@ def test_strided_image(det_mod, oracle):
     hd.close()
 
 
-@pytest.mark.parametrize("mode", ["exact", "fma"])
+@pytest.mark.parametrize("mode", ["exact", "fma", "mfma"])
 def test_conv_pdf(det_mod, oracle, mode):
     from partsbaseddetector_amd import _lib
     flat = M.synthetic_tiny_model().flatten()
-    hd = _handle(det_mod, flat, conv_mode=_lib.CONV_EXACT if mode == "exact" else _lib.CONV_FMA)
+    hd = _handle(det_mod, flat, conv_mode={"exact": _lib.CONV_EXACT, "fma": _lib.CONV_FMA, "mfma": _lib.CONV_MFMA}[mode])
     conv = det_mod.SpatialConvolutionEngine(hd)
     rng = np.random.default_rng(5)
     # ragged levels incl. maps smaller than the filter and one empty level
@@ -301,4 +301,29 @@ def test_f64_detect_end_to_end(det_mod, oracle, which, shape, thresh):
     want = oracle.detect(model.flatten(), im, dtype=np.float64)
     assert len(want) > 0
     _compare_candidates(got, want)
+    det.hd.close()
+
+
+def test_mfma_mode_person_model(det_mod, oracle):
+    """PBD_CONV_MFMA on the 156-filter person model: responses within 1e-4 of the reference order (north-star
+    tolerance); candidates compared with the exact path (identical here; not guaranteed on near ties)."""
+    from partsbaseddetector_amd import _lib
+    model = M.synthetic_person_model(thresh=17.9)
+    flat = model.flatten()
+    im = synth.synthetic_frame(21, 160, 120, 3)
+    det = det_mod.PartsBasedDetector(device=0, conv_mode=_lib.CONV_MFMA)
+    det.distributeModel(model)
+    got = det.detect(im)
+    feats, _ = oracle.features_pyramid(flat, im)
+    worst = 0.0
+    for l in (0, 3, len(feats) - 1):
+        H, W = feats[l].shape[0], feats[l].shape[1] // 32
+        r = det.hd.get_stage(1, 0, l, H, W)
+        worst = max(worst, float(np.abs(r - oracle.responses(flat, feats[l])).max()))
+    assert worst <= 1e-4, worst
+    want = oracle.detect(flat, im)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert (g.level, g.component, g.root[1], g.root[0]) == _cand_key(w)
+        assert np.array_equal(g.parts, w["parts"]) and abs(g.score() - w["score"]) <= 1e-4
     det.hd.close()
