@@ -122,10 +122,12 @@ struct Plan {
     ~Plan() { release(); }
 };
 
-struct Group {   // parts of one tree depth
+struct Group {   // DT jobs of the parts of one tree depth + combine jobs of their parents
     std::vector<DtJob> jobs;
+    std::vector<ChildDesc> childs;
     std::vector<CombineJob> cjobs;
     DevTable<DtJob> d_jobs;
+    DevTable<ChildDesc> d_childs;
     DevTable<CombineJob> d_cjobs;
 };
 
@@ -170,13 +172,12 @@ struct pbd_handle {
     bool own_stream = false;
 
     // model (host copies)
-    int NC = 0, F = 0, flen = 32, sbin = 4, interval = 10, norient = 18, NS = 0, max_parts = 0;
+    int NC = 0, F = 0, flen = 32, sbin = 4, interval = 10, norient = 18, NS = 0, NM = 0, max_parts = 0;
     float thresh = 0.f;
     int ksize = 0, Fpad = 0;
     std::vector<int> filter_ksize, part_offset, parentid, mix_offset, filterid, biasid, defid, ptr_slot, anchors;
     std::vector<float> biasw, defw;
     std::vector<Group> groups;       // deepest first
-    std::vector<int> child_slots;
     std::vector<RootJob> rjobs;
     std::vector<PartWalk> walk;
     std::vector<int> walk_off;
@@ -187,7 +188,7 @@ struct pbd_handle {
     DevBuf d_wts;                    // real-typed weights
     DevBuf d_wrec;                   // bf16 hi/lo weight records of the matrix-core path
     DevTable<float> d_biasw;
-    DevTable<int> d_child_slots, d_walk_off;
+    DevTable<int> d_walk_off;
     DevTable<RootJob> d_rjobs;
     DevTable<PartWalk> d_walk;
     DevBuf d_coord;                  // HogCoordT<R>[]
@@ -202,8 +203,8 @@ struct pbd_handle {
     bool have_features = false, have_resp = false, have_dp = false;
 
     // workspace
-    DevBuf frames, pyr, hist, norm, feat, resp, msg, Ix, Iy, Ik, rootv, rooti;
-    DevBuf tmp, dt, IxRaw, IyRaw, stk, cand, count, scales_tmp;
+    DevBuf frames, pyr, hist, norm, feat, resp, acc, Ix, Iy, Ik, rootv, rooti;
+    DevBuf tmp, dt, IxT, IxRaw, IyRaw, stk, cand, count, scales_tmp;
     std::vector<int32_t> cand_host;
 
     Prof prof;
@@ -559,40 +560,51 @@ int build_model(pbd_handle *h, const pbd_model *m)
         for (int p = np - 1; p > 0; --p) children[p0 + h->parentid[p0 + p]].push_back(p0 + p);
     }
 
-    // depth groups, deepest first; per job the child slot list already includes the job's mixture
+    // depth groups, deepest first: DT jobs of the parts at depth `dep`, combine jobs of their parents
+    h->NM = totmix;
     h->groups.clear();
-    h->child_slots.clear();
     h->JGmax = 0;
     for (int dep = maxdepth; dep >= 1; --dep) {
         Group g;
+        std::vector<int> job_begin_of(totparts, -1);
         for (int c = 0; c < h->NC; ++c) {
             const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
             for (int p = 1; p < np; ++p) {
                 const int gp = p0 + p;
                 if (depth[gp] != dep) continue;
-                const int gpar = p0 + h->parentid[gp];
                 const int K = h->mix_offset[gp + 1] - h->mix_offset[gp];
-                const int L = h->mix_offset[gpar + 1] - h->mix_offset[gpar];
-                const int job_begin = (int)g.jobs.size();
+                job_begin_of[gp] = (int)g.jobs.size();
                 for (int mm = 0; mm < K; ++mm) {
                     const int gm = h->mix_offset[gp] + mm;
                     DtJob j{};
-                    j.filter = h->filterid[gm];
-                    j.child_begin = (int)h->child_slots.size();
-                    for (int ch : children[gp]) h->child_slots.push_back(h->ptr_slot[ch] + mm);
-                    j.child_end = (int)h->child_slots.size();
+                    j.from_acc = children[gp].empty() ? 0 : 1;
+                    j.plane = j.from_acc ? gm : h->filterid[gm];
                     const int d = h->defid[gm];
                     const float *w = &h->defw[(size_t)d * 4];
                     j.ax = (double)(-w[0]); j.bx = (double)(-w[1]); j.ay = (double)(-w[2]); j.by = (double)(-w[3]);
                     j.osx = h->anchors[(size_t)d * 2]; j.osy = h->anchors[(size_t)d * 2 + 1];
                     g.jobs.push_back(j);
                 }
-                {
-                    CombineJob cj{};
-                    cj.job_begin = job_begin; cj.nmix = K; cj.npar = L; cj.slot = h->ptr_slot[gp];
-                    for (int mm = 0; mm < K; ++mm) cj.bias_off[mm] = h->biasid[h->mix_offset[gp] + mm];
-                    g.cjobs.push_back(cj);
+            }
+            // parents at depth dep-1 whose children (all at depth dep) were just listed
+            for (int p = 0; p < np; ++p) {
+                const int gpar = p0 + p;
+                if (depth[gpar] != dep - 1 || children[gpar].empty()) continue;
+                const int L = h->mix_offset[gpar + 1] - h->mix_offset[gpar];
+                CombineJob cj{};
+                cj.npar = L; cj.acc_plane = h->mix_offset[gpar];
+                for (int pm = 0; pm < L; ++pm) cj.filter[pm] = h->filterid[h->mix_offset[gpar] + pm];
+                cj.child_begin = (int)g.childs.size();
+                for (int ch : children[gpar]) {   // already in descending index order
+                    ChildDesc cd{};
+                    cd.job_begin = job_begin_of[ch];
+                    cd.nmix = h->mix_offset[ch + 1] - h->mix_offset[ch];
+                    cd.slot = h->ptr_slot[ch];
+                    for (int mm = 0; mm < cd.nmix; ++mm) cd.bias_off[mm] = h->biasid[h->mix_offset[ch] + mm];
+                    g.childs.push_back(cd);
                 }
+                cj.child_end = (int)g.childs.size();
+                g.cjobs.push_back(cj);
             }
         }
         h->JGmax = std::max(h->JGmax, (int)g.jobs.size());
@@ -600,19 +612,17 @@ int build_model(pbd_handle *h, const pbd_model *m)
     }
     for (auto &g : h->groups) {
         HIPCHK(h, g.d_jobs.upload(g.jobs));
+        HIPCHK(h, g.d_childs.upload(g.childs));
         HIPCHK(h, g.d_cjobs.upload(g.cjobs));
     }
-    // roots: child list holds base slots (mixture added in the kernel)
     h->rjobs.assign(h->NC, RootJob{});
     h->walk.clear(); h->walk_off.assign(h->NC + 1, 0);
     for (int c = 0; c < h->NC; ++c) {
         const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
         RootJob &r = h->rjobs[c];
         r.nmix = h->mix_offset[p0 + 1] - h->mix_offset[p0];
-        for (int mm = 0; mm < r.nmix; ++mm) r.filter[mm] = h->filterid[h->mix_offset[p0] + mm];
-        r.child_begin = (int)h->child_slots.size();
-        for (int ch : children[p0]) h->child_slots.push_back(h->ptr_slot[ch]);
-        r.child_end = (int)h->child_slots.size();
+        r.from_acc = children[p0].empty() ? 0 : 1;
+        for (int mm = 0; mm < r.nmix; ++mm) r.plane[mm] = r.from_acc ? h->mix_offset[p0] + mm : h->filterid[h->mix_offset[p0] + mm];
         r.bias = h->biasw[h->biasid[h->mix_offset[p0]]];
         h->walk_off[c] = (int)h->walk.size();
         for (int p = 0; p < np; ++p) {
@@ -625,7 +635,6 @@ int build_model(pbd_handle *h, const pbd_model *m)
         }
     }
     h->walk_off[h->NC] = (int)h->walk.size();
-    HIPCHK(h, h->d_child_slots.upload(h->child_slots));
     HIPCHK(h, h->d_rjobs.upload(h->rjobs));
     HIPCHK(h, h->d_walk.upload(h->walk));
     HIPCHK(h, h->d_walk_off.upload(h->walk_off));
@@ -709,7 +718,7 @@ int dp_chunk_frames(pbd_handle *h, Plan &P, int want)
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     const size_t budget = (size_t)8 << 30;   // bytes of scratch per chunk (14 B / cell-job + 12 B / stack entry)
     int chunk = std::max(want, 1);
-    while (chunk > 1 && (per_frame * (6 + 2 * h->rs) + stk_per_frame * (h->f64 ? kStkEntryF64 : kStkEntryF32)) * chunk > budget) chunk = (chunk + 1) / 2;
+    while (chunk > 1 && (per_frame * (8 + 2 * h->rs) + stk_per_frame * (h->f64 ? kStkEntryF64 : kStkEntryF32)) * chunk > budget) chunk = (chunk + 1) / 2;
     return chunk;
 }
 
@@ -717,7 +726,7 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
 {
     const size_t cpf = (size_t)P.cell_per_frame;
     const int NSa = std::max(h->NS, 1);
-    HIPCHK(h, h->msg.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * h->rs, 16)));
+    HIPCHK(h, h->acc.ensure(std::max<size_t>((size_t)nframes * cpf * std::max(h->NM, 1) * h->rs, 16)));
     HIPCHK(h, h->Ix.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(int16_t), 16)));
     HIPCHK(h, h->Iy.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(int16_t), 16)));
     HIPCHK(h, h->Ik.ensure(std::max<size_t>((size_t)nframes * cpf * NSa, 16)));
@@ -727,7 +736,8 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
     HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
-    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int), 16)));
+    HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * sizeof(int), 16)));
+    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkEntryF64 : kStkEntryF32), 16)));
     return PBD_OK;
@@ -737,22 +747,22 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
 void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
 {
     DpParams dp{};
-    dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC;
+    dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC; dp.NM = h->NM;
     dp.cell_per_frame = P.cell_per_frame;
-    dp.resp = h->resp.p; dp.msg = h->msg.p;
+    dp.resp = h->resp.p; dp.acc = h->acc.p;
     dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;
-    dp.IxRaw32 = h->IxRaw.as<int>(); dp.IyRaw = h->IyRaw.as<int16_t>();
+    dp.IxT = h->IxT.as<int>(); dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
     dp.stk = h->stk.p; dp.stk_per_jf = P.stk_per_jf;
     dp.stk_row_off = P.d_stk_row_off.d; dp.stk_col_off = P.d_stk_col_off.d;
-    dp.child_slots = h->d_child_slots.d; dp.biasw = h->d_biasw.d;
+    dp.biasw = h->d_biasw.d;
     dp.row2level = P.d_row2level.d; dp.rowoff = P.d_rowoff.d; dp.col2level = P.d_col2level.d; dp.coloff = P.d_coloff.d;
     dp.nrows_flat = P.nrows_flat; dp.ncols_flat = P.ncols_flat;
     dp.rootv = h->rootv.p; dp.rooti = h->rooti.as<int>(); dp.rjobs = h->d_rjobs.d;
     dp.frame0 = f0;
     for (auto &g : h->groups) {
         dp.JG = (int)g.jobs.size();
-        dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d;
+        dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d; dp.childs = g.d_childs.d;
         { ProfScope ps(h, PBD_K_DT_ROWS, st); launch_dt_rows(dp, nb, h->f64, st); }
         { ProfScope ps(h, PBD_K_DT_COLS, st); launch_dt_cols(dp, nb, h->f64, st); }
         { ProfScope ps(h, PBD_K_DP_COMBINE, st); launch_dp_combine(dp, (int)g.cjobs.size(), nb, h->f64, st); }
@@ -975,13 +985,13 @@ void pbd_destroy(pbd_handle *h)
     h->prof.release();
     for (auto e : h->chunk_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    for (DevBuf *b : {&h->frames, &h->pyr, &h->hist, &h->norm, &h->feat, &h->resp, &h->msg, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
-                      &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
+    for (DevBuf *b : {&h->frames, &h->pyr, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
+                      &h->rooti, &h->tmp, &h->dt, &h->IxT, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();
-    h->d_wts.release(); h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_child_slots.release(); h->d_walk_off.release();
+    h->d_wts.release(); h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_walk_off.release();
     h->d_rjobs.release(); h->d_walk.release();
-    for (auto &g : h->groups) { g.d_jobs.release(); g.d_cjobs.release(); }
+    for (auto &g : h->groups) { g.d_jobs.release(); g.d_childs.release(); g.d_cjobs.release(); }
     h->plans.clear();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

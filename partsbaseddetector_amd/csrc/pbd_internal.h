@@ -36,27 +36,38 @@ typedef HogCoordT<double> HogCoordD;
 
 struct ConvTile { int level; int y0, x0; };
 
-// distance-transform job = (part, child mixture) of one tree-depth group
+// distance-transform job = (part, mixture) of one tree-depth group.  Its input is ONE plane: the raw
+// response of its filter for a leaf part, or the accumulated score (response + children's messages,
+// written by the combine step of the deeper group) otherwise.
 struct DtJob {
-    int filter;               // response plane of this (part, mixture)
-    int child_begin, child_end; // range in the child-slot list (already in descending child order)
+    int plane;                // filter id (from_acc == 0) or global mixture index (from_acc == 1)
+    int from_acc;
     int osx, osy;             // anchor
     double ax, bx, ay, by;    // Quadratic(-w0,-w1), Quadratic(-w2,-w3)  (src/DynamicProgram.cpp:125-127)
 };
 
-// combine job = (part, parent mixture) of one tree-depth group
-struct CombineJob {           // one per part of the group (all parent mixtures)
-    int job_begin;            // first DtJob (index within the group) of this part
+// one child part of a combine job
+struct ChildDesc {
+    int job_begin;            // first DtJob (index within the group) of this child
     int nmix;                 // child mixtures K
-    int npar;                 // parent mixtures L
-    int slot;                 // back-pointer / message slot of parent mixture 0 = ptr_slot[part]
-    int bias_off[8];          // biasid[part][mm], mm < K (add the parent mixture)   (K <= 8)
+    int slot;                 // back-pointer slot of (child, parent mixture 0) = ptr_slot[child]
+    int bias_off[8];          // biasid[child][mm], mm < K (add the parent mixture)
+};
+
+// combine job = one PARENT part: for every parent mixture m
+//   acc[m] = response(parent, m); for each child in DESCENDING index order: acc[m] += max_mm(dt[child][mm] + bias)
+// (the order of the reference's in-place `parent.score += maxv`, src/DynamicProgram.cpp:95,154-156)
+struct CombineJob {
+    int child_begin, child_end;   // range in the ChildDesc list, descending child index
+    int npar;                     // parent mixtures L
+    int acc_plane;                // global mixture index of (parent, mixture 0)
+    int filter[8];                // response plane of (parent, m)
 };
 
 struct RootJob {              // one per component
     int nmix;
-    int filter[8];
-    int child_begin, child_end;
+    int plane[8];             // filter id or global mixture index per root mixture
+    int from_acc;
     float bias;
 };
 
@@ -113,23 +124,24 @@ struct ConvParams {
 struct DpParams {
     const LevelDesc *lv;
     int nlevels;
-    int F, NS, NC;                // filters, pointer slots, components
+    int F, NS, NC, NM;            // filters, pointer slots, components, (part, mixture) pairs
     long long cell_per_frame;
     int frame0;                   // first frame of this chunk (absolute index into resp/msg/ptr buffers)
     const void *resp;             // R
-    void *msg;                    // R [frames][cell_per_frame*NS]
+    void *acc;                    // R [frames][cell_per_frame*NM] accumulated scores of non-leaf parts
     int16_t *Ix, *Iy;             // [frames][cell_per_frame*NS]
     uint8_t *Ik;
     // group scratch, indexed by chunk-local frame
     int JG;                       // jobs in this group
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
-    int *IxRaw32; int16_t *IyRaw;
+    int *IxT;                     // rows-pass pointers, transposed [x][y]
+    int16_t *IxRaw, *IyRaw;       // row-major pointers written by the columns pass
     void *stk;                    // [chunk][JG][stk_per_jf] 12-byte entries, wave-private, lane-interleaved
     long long stk_per_jf;         // entries per (job, frame)
     const long long *stk_row_off; // per rows-pass wave (64 flat rows): first entry
     const long long *stk_col_off; // per columns-pass wave
     const DtJob *jobs;
-    const int *child_slots;
+    const ChildDesc *childs;
     const CombineJob *cjobs;
     const float *biasw;
     const int *row2level; const int *rowoff;   // flat row -> level, level -> first flat row

@@ -50,7 +50,10 @@ template <typename R> struct StkEntryT { R z; R s; int v; };
 static_assert(sizeof(StkEntryT<float>) == kStkEntryF32 && sizeof(StkEntryT<double>) == kStkEntryF64, "host sizes the spill stack with these");
 
 constexpr int kDtCH = 8;
-constexpr int kDtT = 16;    // ring entries per lane
+#ifndef PBD_DT_RING
+#define PBD_DT_RING 8
+#endif
+constexpr int kDtT = PBD_DT_RING;    // ring entries per lane (power of two)
 
 template <typename R>
 struct DtRing {
@@ -79,8 +82,11 @@ struct DtRing {
     }
 };
 
-template <typename R, class LoadChunk, class StoreChunk>
-__device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store)
+// AUX: the read-out additionally streams an int chunk per output chunk (prefetched one chunk ahead, q
+// descending) and hands it to `store` -- the columns pass uses it to carry the rows pass's pointers along.
+template <typename R, bool AUX, class LoadChunk, class StoreChunk, class AuxChunk>
+__device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store,
+                                          AuxChunk aux)
 {
     constexpr int CH = kDtCH;
     R cur[CH], nxt[CH];
@@ -111,8 +117,13 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
     }
     // read-out, q descending
     const int nch = (N + CH - 1) / CH;
+    int aux_cur[CH], aux_nxt[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { aux_cur[i] = 0; aux_nxt[i] = 0; }
+    if (AUX) aux((nch - 1) * CH, aux_cur);
     for (int cidx = nch - 1; cidx >= 0; --cidx) {
         const int q0 = cidx * CH;
+        if (AUX && cidx > 0) aux(q0 - CH, aux_nxt);
         R out[CH];
         int ptr[CH];
 #pragma unroll
@@ -129,7 +140,11 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
                 ptr[i] = vk;
             }
         }
-        store(q0, out, ptr);
+        store(q0, out, ptr, aux_cur);
+        if (AUX) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) aux_cur[i] = aux_nxt[i];
+        }
     }
 }
 
@@ -150,18 +165,20 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
     const int W = d.cols;
     const size_t HW = (size_t)d.rows * W;
     const DtJob job = p.jobs[j];
-    const R *src = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)job.filter * HW + (size_t)y * W;
-    const R *msg_row = static_cast<const R *>(p.msg) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + (size_t)y * W;
-    const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y * W;
-    R *tmp = static_cast<R *>(p.tmp) + obase;
-    int *ixr = p.IxRaw32 + obase;
+    const R *src = (job.from_acc ? static_cast<const R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM
+                                 : static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F) +
+                   (size_t)job.plane * HW + (size_t)y * W;
+    // outputs go out TRANSPOSED ([x][y]): lanes are adjacent rows y, so every store instruction writes
+    // whole lines; the columns pass reads its own column back with wide per-lane loads
+    const int Hl = d.rows;
+    const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y;
+    R *tmpT = static_cast<R *>(p.tmp) + obase;
+    int *ixT = p.IxT + obase;
     __shared__ R ring_z[kDtT * 64], ring_s[kDtT * 64];
     __shared__ int ring_v[kDtT * 64];
     DtRing<R> ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
                    reinterpret_cast<StkEntryT<R> *>(p.stk) +
                        ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[blockIdx.x]) + threadIdx.x, 0};
-    const int *cs = p.child_slots;
-    const int cb = job.child_begin, ce = job.child_end;
     const int N = active ? W : 0;
     if (N == 0) return;
     auto load = [&](int q0, R *buf) {
@@ -169,38 +186,18 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
             const float *srcf = reinterpret_cast<const float *>(src);
             const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0), a1 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4);
             buf[0] = a0.x; buf[1] = a0.y; buf[2] = a0.z; buf[3] = a0.w; buf[4] = a1.x; buf[5] = a1.y; buf[6] = a1.z; buf[7] = a1.w;
-            for (int c = cb; c < ce; ++c) {   // children's messages, descending child order
-                const float *m = reinterpret_cast<const float *>(msg_row + (size_t)cs[c] * HW) + q0;
-                const v4f_u m0 = *reinterpret_cast<const v4f_u *>(m), m1 = *reinterpret_cast<const v4f_u *>(m + 4);
-                buf[0] = buf[0] + m0.x; buf[1] = buf[1] + m0.y; buf[2] = buf[2] + m0.z; buf[3] = buf[3] + m0.w;
-                buf[4] = buf[4] + m1.x; buf[5] = buf[5] + m1.y; buf[6] = buf[6] + m1.z; buf[7] = buf[7] + m1.w;
-            }
         } else {
 #pragma unroll
-            for (int i = 0; i < kDtCH; ++i) {
-                R v = (R)0;
-                if (q0 + i < N) {
-                    v = src[q0 + i];
-                    for (int c = cb; c < ce; ++c) v = v + msg_row[(size_t)cs[c] * HW + q0 + i];
-                }
-                buf[i] = v;
-            }
+            for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < N) ? src[q0 + i] : (R)0;
         }
     };
-    auto store = [&](int q0, const R *out, const int *ptr) {
-        if (sizeof(R) == 4 && q0 + kDtCH <= N) {
-            float *tmpf = reinterpret_cast<float *>(tmp);
-            *reinterpret_cast<v4f_u *>(tmpf + q0) = v4f_u{(float)out[0], (float)out[1], (float)out[2], (float)out[3]};
-            *reinterpret_cast<v4f_u *>(tmpf + q0 + 4) = v4f_u{(float)out[4], (float)out[5], (float)out[6], (float)out[7]};
-            *reinterpret_cast<v4i_u *>(ixr + q0) = v4i_u{ptr[0], ptr[1], ptr[2], ptr[3]};
-            *reinterpret_cast<v4i_u *>(ixr + q0 + 4) = v4i_u{ptr[4], ptr[5], ptr[6], ptr[7]};
-        } else {
+    auto store = [&](int q0, const R *out, const int *ptr, const int *) {
 #pragma unroll
-            for (int i = 0; i < kDtCH; ++i)
-                if (q0 + i < N) { tmp[q0 + i] = out[i]; ixr[q0 + i] = ptr[i]; }
-        }
+        for (int i = 0; i < kDtCH; ++i)
+            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = ptr[i]; }
     };
-    dt_stream<R>(N, job.ax, job.bx, job.osx, ring, load, store);
+    auto noaux = [](int, int *) {};
+    dt_stream<R, false>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
 }
 
 void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
@@ -224,25 +221,46 @@ __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
     const int H = d.rows, W = d.cols;
     const size_t HW = (size_t)H * W;
     const DtJob job = p.jobs[j];
-    const size_t base = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + x;
-    const R *tmp = static_cast<const R *>(p.tmp) + base;
-    R *dt = static_cast<R *>(p.dt) + base;
-    int16_t *iyr = p.IyRaw + base;
+    const size_t jbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
+    const R *tmpT = static_cast<const R *>(p.tmp) + jbase + (size_t)x * H;     // this lane's column, contiguous
+    const int *ixT = p.IxT + jbase + (size_t)x * H;
+    R *dt = static_cast<R *>(p.dt) + jbase + x;
+    int16_t *iyr = p.IyRaw + jbase + x;
+    int16_t *ixr = p.IxRaw + jbase + x;
     __shared__ R ring_z[kDtT * 64], ring_s[kDtT * 64];
     __shared__ int ring_v[kDtT * 64];
     DtRing<R> ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
                    reinterpret_cast<StkEntryT<R> *>(p.stk) +
                        ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[blockIdx.x]) + threadIdx.x, 0};
     auto load = [&](int q0, R *buf) {
+        if (sizeof(R) == 4 && q0 + kDtCH <= H) {
+            const float *srcf = reinterpret_cast<const float *>(tmpT);
+            const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0), a1 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4);
+            buf[0] = a0.x; buf[1] = a0.y; buf[2] = a0.z; buf[3] = a0.w; buf[4] = a1.x; buf[5] = a1.y; buf[6] = a1.z; buf[7] = a1.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmp[(size_t)(q0 + i) * W] : (R)0;
+            for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmpT[q0 + i] : (R)0;
+        }
     };
-    auto store = [&](int q0, const R *out, const int *ptr) {
+    auto aux = [&](int q0, int *buf) {      // the rows pass's pointers of this column
+        if (q0 + kDtCH <= H) {
+            const v4i_u a0 = *reinterpret_cast<const v4i_u *>(ixT + q0), a1 = *reinterpret_cast<const v4i_u *>(ixT + q0 + 4);
+            buf[0] = a0.x; buf[1] = a0.y; buf[2] = a0.z; buf[3] = a0.w; buf[4] = a1.x; buf[5] = a1.y; buf[6] = a1.z; buf[7] = a1.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? ixT[q0 + i] : 0;
+        }
+    };
+    auto store = [&](int q0, const R *out, const int *ptr, const int *ix) {
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i)
-            if (q0 + i < H) { dt[(size_t)(q0 + i) * W] = out[i]; iyr[(size_t)(q0 + i) * W] = (int16_t)ptr[i]; }
+            if (q0 + i < H) {
+                dt[(size_t)(q0 + i) * W] = out[i];
+                iyr[(size_t)(q0 + i) * W] = (int16_t)ptr[i];
+                ixr[(size_t)(q0 + i) * W] = (int16_t)ix[i];
+            }
     };
-    dt_stream<R>(H, job.ay, job.by, job.osy, ring, load, store);
+    dt_stream<R, true>(H, job.ay, job.by, job.osy, ring, load, store, aux);
 }
 
 void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
@@ -253,10 +271,12 @@ void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
     else hipLaunchKernelGGL(k_dt_cols<float>, grid, dim3(64), 0, s, p);
 }
 
-// ---- combine: thread = cell of one part (block.y), all parent mixtures -------------------------------
-// weighted[mm] = score_dt[mm] + bias(mm)[m]; reduceMax (strict >, first wins, start -inf; K==1 copies);
-// Ix/Iy picked from the winning mixture, with the reference's Iy composition
-// Iy[y][x] = IyRaw[y][Ix[y][x]] (include/DistanceTransform.hpp:233-244); message = max value.
+// ---- combine: thread = cell of one PARENT part (block.y) ---------------------------------------------
+// For every parent mixture m: acc = response(parent, m); then for each child in descending index order
+//   weighted[mm] = score_dt[child][mm] + bias(mm)[m]; reduceMax (strict >, first wins, start -inf; K==1 copies);
+//   Ix/Iy picked from the winning mixture with the reference's composition Iy[y][x] = IyRaw[y][Ix[y][x]]
+//   (include/DistanceTransform.hpp:233-244); acc += max   (src/DynamicProgram.cpp:134-156).
+// The accumulated plane is the input of the parent's own distance transform in the next group.
 template <typename R>
 __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
 {
@@ -271,42 +291,56 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
     const int W = d.cols;
     const size_t HW = (size_t)d.rows * W;
     const int y = local / W;
-    const size_t gbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)cj.job_begin * HW;
+    const R *resp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
     const R *dtp = static_cast<const R *>(p.dt);
-    R dtv[kMaxMix];
-    int ixv[kMaxMix];
+    const size_t gbase0 = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG;
+    const size_t pbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + local;
+    R accv[kMaxMix];
 #pragma unroll
-    for (int mm = 0; mm < kMaxMix; ++mm) {
-        dtv[mm] = (R)0; ixv[mm] = 0;
-        if (mm < cj.nmix) {
-            dtv[mm] = dtp[gbase + (size_t)mm * HW + local];
-            ixv[mm] = p.IxRaw32[gbase + (size_t)mm * HW + local];
-        }
-    }
-    const size_t obase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + (size_t)cj.slot * HW + local;
-    R *msg = static_cast<R *>(p.msg);
-    for (int pm = 0; pm < cj.npar; ++pm) {
-        R best;
-        int bi = 0, ix = ixv[0];
-        if (cj.nmix == 1) {
-            best = dtv[0] + (R)p.biasw[cj.bias_off[0] + pm];
-        } else {
-            best = -RealLimits<R>::inf();
+    for (int pm = 0; pm < kMaxMix; ++pm) accv[pm] = (pm < cj.npar) ? resp[(size_t)cj.filter[pm] * HW + local] : (R)0;
+    for (int ch = cj.child_begin; ch < cj.child_end; ++ch) {
+        const ChildDesc cd = p.childs[ch];
+        const size_t gbase = gbase0 + (size_t)cd.job_begin * HW;
+        R dtv[kMaxMix];
+        int ixv[kMaxMix];
 #pragma unroll
-            for (int mm = 0; mm < kMaxMix; ++mm) {
-                if (mm < cj.nmix) {
-                    const R wv = dtv[mm] + (R)p.biasw[cj.bias_off[mm] + pm];
-                    if (wv > best) { bi = mm; best = wv; ix = ixv[mm]; }
-                }
+        for (int mm = 0; mm < kMaxMix; ++mm) {
+            dtv[mm] = (R)0; ixv[mm] = 0;
+            if (mm < cd.nmix) {
+                dtv[mm] = dtp[gbase + (size_t)mm * HW + local];
+                ixv[mm] = p.IxRaw[gbase + (size_t)mm * HW + local];
             }
         }
-        const int iy = p.IyRaw[gbase + (size_t)bi * HW + (size_t)y * W + ix];
-        const size_t o = obase + (size_t)pm * HW;
-        p.Ix[o] = (int16_t)ix;
-        p.Iy[o] = (int16_t)iy;
-        p.Ik[o] = (uint8_t)bi;
-        msg[o] = best;
+#pragma unroll
+        for (int pm = 0; pm < kMaxMix; ++pm) {
+            if (pm < cj.npar) {
+                R best;
+                int bi = 0, ix = ixv[0];
+                if (cd.nmix == 1) {
+                    best = dtv[0] + (R)p.biasw[cd.bias_off[0] + pm];
+                } else {
+                    best = -RealLimits<R>::inf();
+#pragma unroll
+                    for (int mm = 0; mm < kMaxMix; ++mm) {
+                        if (mm < cd.nmix) {
+                            const R wv = dtv[mm] + (R)p.biasw[cd.bias_off[mm] + pm];
+                            if (wv > best) { bi = mm; best = wv; ix = ixv[mm]; }
+                        }
+                    }
+                }
+                const int iy = p.IyRaw[gbase + (size_t)bi * HW + (size_t)y * W + ix];
+                const size_t o = pbase + (size_t)(cd.slot + pm) * HW;
+                p.Ix[o] = (int16_t)ix;
+                p.Iy[o] = (int16_t)iy;
+                p.Ik[o] = (uint8_t)bi;
+                accv[pm] = accv[pm] + best;
+            }
+        }
     }
+    R *acc = static_cast<R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM + local;
+#pragma unroll
+    for (int pm = 0; pm < kMaxMix; ++pm)
+        if (pm < cj.npar) acc[(size_t)(cj.acc_plane + pm) * HW] = accv[pm];
 }
 
 void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hipStream_t s)
@@ -330,22 +364,16 @@ __global__ __launch_bounds__(256) void k_dp_root(DpParams p)
     const LevelDesc d = p.lv[lo];
     const int local = (int)(idx - d.cell_off);
     const size_t HW = (size_t)d.rows * d.cols;
-    const R *resp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
-    const R *msg_base = static_cast<const R *>(p.msg) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS;
+    const R *src = rj.from_acc ? static_cast<const R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM
+                               : static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
     R best;
     int bi = 0;
     if (rj.nmix == 1) {
-        R v = resp[(size_t)rj.filter[0] * HW + local];
-        for (int k = rj.child_begin; k < rj.child_end; ++k) v = v + msg_base[(size_t)p.child_slots[k] * HW + local];
-        best = v + (R)rj.bias;
+        best = src[(size_t)rj.plane[0] * HW + local] + (R)rj.bias;
     } else {
         best = -RealLimits<R>::inf();
         for (int mm = 0; mm < rj.nmix; ++mm) {
-            R v = resp[(size_t)rj.filter[mm] * HW + local];
-            // message slot of child k towards root mixture mm = child_slots[k] + mm
-            for (int k = rj.child_begin; k < rj.child_end; ++k)
-                v = v + msg_base[(size_t)(p.child_slots[k] + mm) * HW + local];
-            const R wv = v + (R)rj.bias;
+            const R wv = src[(size_t)rj.plane[mm] * HW + local] + (R)rj.bias;
             if (wv > best) { bi = mm; best = wv; }
         }
     }
