@@ -49,7 +49,14 @@ template <> struct RealLimits<double> { static __device__ __forceinline__ double
 template <typename R> struct StkEntryT { R z; R s; int v; };
 static_assert(sizeof(StkEntryT<float>) == kStkEntryF32 && sizeof(StkEntryT<double>) == kStkEntryF64, "host sizes the spill stack with these");
 
-constexpr int kDtCH = 8;
+#ifndef PBD_DT_CH
+#define PBD_DT_CH 8
+#endif
+constexpr int kDtCH = PBD_DT_CH;   // elements per streamed chunk (multiple of 4)
+#ifndef PBD_DT_WAVES
+#define PBD_DT_WAVES 4
+#endif
+constexpr int kDtWaves = PBD_DT_WAVES;   // waves per workgroup of the DT passes (each wave = 64 rows / columns)
 #ifndef PBD_DT_RING
 #define PBD_DT_RING 8
 #endif
@@ -153,9 +160,11 @@ typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
 template <typename R>
-__global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
+__global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
-    const int r = blockIdx.x * 64 + threadIdx.x;
+    const int wv = blockIdx.x * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv * 64 >= p.nrows_flat) return;
+    const int r = wv * 64 + lane;
     const bool active = r < p.nrows_flat;
     const int rr = active ? r : p.nrows_flat - 1;
     const int j = blockIdx.y, fl = blockIdx.z, frame = p.frame0 + fl;
@@ -174,18 +183,22 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
     const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y;
     R *tmpT = static_cast<R *>(p.tmp) + obase;
     int *ixT = p.IxT + obase;
-    __shared__ R ring_z[kDtT * 64], ring_s[kDtT * 64];
-    __shared__ int ring_v[kDtT * 64];
-    DtRing<R> ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
+    __shared__ R ring_z[kDtWaves * kDtT * 64], ring_s[kDtWaves * kDtT * 64];
+    __shared__ int ring_v[kDtWaves * kDtT * 64];
+    const int ro = (threadIdx.x >> 6) * (kDtT * 64) + lane;
+    DtRing<R> ring{ring_z + ro, ring_s + ro, ring_v + ro,
                    reinterpret_cast<StkEntryT<R> *>(p.stk) +
-                       ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[blockIdx.x]) + threadIdx.x, 0};
+                       ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane, 0};
     const int N = active ? W : 0;
     if (N == 0) return;
     auto load = [&](int q0, R *buf) {
         if (sizeof(R) == 4 && q0 + kDtCH <= N) {
             const float *srcf = reinterpret_cast<const float *>(src);
-            const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0), a1 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4);
-            buf[0] = a0.x; buf[1] = a0.y; buf[2] = a0.z; buf[3] = a0.w; buf[4] = a1.x; buf[5] = a1.y; buf[6] = a1.z; buf[7] = a1.w;
+#pragma unroll
+            for (int v = 0; v < kDtCH / 4; ++v) {
+                const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4 * v);
+                buf[4 * v] = a0.x; buf[4 * v + 1] = a0.y; buf[4 * v + 2] = a0.z; buf[4 * v + 3] = a0.w;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < N) ? src[q0 + i] : (R)0;
@@ -203,16 +216,18 @@ __global__ __launch_bounds__(64) void k_dt_rows(DpParams p)
 void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.JG == 0 || p.nrows_flat == 0) return;
-    dim3 grid((p.nrows_flat + 63) / 64, p.JG, nframes);
-    if (f64) hipLaunchKernelGGL(k_dt_rows<double>, grid, dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(k_dt_rows<float>, grid, dim3(64), 0, s, p);
+    const int nwv = (p.nrows_flat + 63) / 64;
+    dim3 grid((nwv + kDtWaves - 1) / kDtWaves, p.JG, nframes);
+    if (f64) hipLaunchKernelGGL(k_dt_rows<double>, grid, dim3(64 * kDtWaves), 0, s, p);
+    else hipLaunchKernelGGL(k_dt_rows<float>, grid, dim3(64 * kDtWaves), 0, s, p);
 }
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
 template <typename R>
-__global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
+__global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
 {
-    const int cidx = blockIdx.x * 64 + threadIdx.x;
+    const int wv = blockIdx.x * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cidx = wv * 64 + lane;
     if (cidx >= p.ncols_flat) return;
     const int j = blockIdx.y, fl = blockIdx.z;
     const int l = p.col2level[cidx];
@@ -227,16 +242,20 @@ __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
     R *dt = static_cast<R *>(p.dt) + jbase + x;
     int16_t *iyr = p.IyRaw + jbase + x;
     int16_t *ixr = p.IxRaw + jbase + x;
-    __shared__ R ring_z[kDtT * 64], ring_s[kDtT * 64];
-    __shared__ int ring_v[kDtT * 64];
-    DtRing<R> ring{ring_z + threadIdx.x, ring_s + threadIdx.x, ring_v + threadIdx.x,
+    __shared__ R ring_z[kDtWaves * kDtT * 64], ring_s[kDtWaves * kDtT * 64];
+    __shared__ int ring_v[kDtWaves * kDtT * 64];
+    const int ro = (threadIdx.x >> 6) * (kDtT * 64) + lane;
+    DtRing<R> ring{ring_z + ro, ring_s + ro, ring_v + ro,
                    reinterpret_cast<StkEntryT<R> *>(p.stk) +
-                       ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[blockIdx.x]) + threadIdx.x, 0};
+                       ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane, 0};
     auto load = [&](int q0, R *buf) {
         if (sizeof(R) == 4 && q0 + kDtCH <= H) {
             const float *srcf = reinterpret_cast<const float *>(tmpT);
-            const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0), a1 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4);
-            buf[0] = a0.x; buf[1] = a0.y; buf[2] = a0.z; buf[3] = a0.w; buf[4] = a1.x; buf[5] = a1.y; buf[6] = a1.z; buf[7] = a1.w;
+#pragma unroll
+            for (int v = 0; v < kDtCH / 4; ++v) {
+                const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4 * v);
+                buf[4 * v] = a0.x; buf[4 * v + 1] = a0.y; buf[4 * v + 2] = a0.z; buf[4 * v + 3] = a0.w;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmpT[q0 + i] : (R)0;
@@ -244,8 +263,11 @@ __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
     };
     auto aux = [&](int q0, int *buf) {      // the rows pass's pointers of this column
         if (q0 + kDtCH <= H) {
-            const v4i_u a0 = *reinterpret_cast<const v4i_u *>(ixT + q0), a1 = *reinterpret_cast<const v4i_u *>(ixT + q0 + 4);
-            buf[0] = a0.x; buf[1] = a0.y; buf[2] = a0.z; buf[3] = a0.w; buf[4] = a1.x; buf[5] = a1.y; buf[6] = a1.z; buf[7] = a1.w;
+#pragma unroll
+            for (int v = 0; v < kDtCH / 4; ++v) {
+                const v4i_u a0 = *reinterpret_cast<const v4i_u *>(ixT + q0 + 4 * v);
+                buf[4 * v] = a0.x; buf[4 * v + 1] = a0.y; buf[4 * v + 2] = a0.z; buf[4 * v + 3] = a0.w;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? ixT[q0 + i] : 0;
@@ -266,9 +288,10 @@ __global__ __launch_bounds__(64) void k_dt_cols(DpParams p)
 void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.JG == 0 || p.ncols_flat == 0) return;
-    dim3 grid((p.ncols_flat + 63) / 64, p.JG, nframes);
-    if (f64) hipLaunchKernelGGL(k_dt_cols<double>, grid, dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(k_dt_cols<float>, grid, dim3(64), 0, s, p);
+    const int nwv = (p.ncols_flat + 63) / 64;
+    dim3 grid((nwv + kDtWaves - 1) / kDtWaves, p.JG, nframes);
+    if (f64) hipLaunchKernelGGL(k_dt_cols<double>, grid, dim3(64 * kDtWaves), 0, s, p);
+    else hipLaunchKernelGGL(k_dt_cols<float>, grid, dim3(64 * kDtWaves), 0, s, p);
 }
 
 // ---- combine: thread = cell of one PARENT part (block.y) ---------------------------------------------

@@ -327,3 +327,20 @@ def test_mfma_mode_person_model(det_mod, oracle):
         assert (g.level, g.component, g.root[1], g.root[0]) == _cand_key(w)
         assert np.array_equal(g.parts, w["parts"]) and abs(g.score() - w["score"]) <= 1e-4
     det.hd.close()
+
+
+def test_mfma_more_than_one_filter_block(det_mod, oracle):
+    """PBD_CONV_MFMA sweeps the filters in blocks of 160: 170 filters need two passes."""
+    from partsbaseddetector_amd import _lib
+    flat = M.synthetic_tiny_model().flatten()
+    hd = _handle(det_mod, flat, conv_mode=_lib.CONV_MFMA)
+    conv = det_mod.SpatialConvolutionEngine(hd)
+    rng = np.random.default_rng(12)
+    filters = [rng.standard_normal((5, 5 * 32)).astype(np.float32) * 0.05 for _ in range(170)]
+    conv.setFilters(filters)
+    feat = rng.random((19, 37 * 32), dtype=np.float32) * 0.4
+    got = conv.pdf([feat])[0]
+    assert got.shape == (170, 19, 37)
+    for f in (0, 31, 159, 160, 169):
+        assert np.abs(got[f] - oracle.conv(feat, filters[f])).max() <= 1e-4
+    hd.close()
