@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the same workload timed on the host CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-exact-ref", action="store_true", help="skip the exact-mode reference run / agreement check")
     return ap.parse_args()
 
 
@@ -200,7 +201,7 @@ def main():
             cpu = {"value": round(nf / cdt, 4), "unit": "detections/s", "cores": oracle.num_threads(), "kind": "port",
                    "sample": f"{nf} of the same 640x480 frames, full path, OpenMP at the reference's 5 sites"}
         exact_mode, agreement = None, None
-        if world == 1 and args.conv_mode != "exact":
+        if world == 1 and args.conv_mode != "exact" and not args.no_exact_ref:
             last = np.array(det._buf[:ncand * stride]).reshape(ncand, stride).copy()
             det2 = PartsBasedDetector(device=local_rank, conv_mode=_lib.CONV_EXACT, max_batch=B, max_candidates=cap)
             det2.distributeModel(model)
