@@ -54,7 +54,7 @@ static_assert(sizeof(StkEntryT<float>) == kStkEntryF32 && sizeof(StkEntryT<doubl
 #endif
 constexpr int kDtCH = PBD_DT_CH;   // elements per streamed chunk (multiple of 4)
 #ifndef PBD_DT_WAVES
-#define PBD_DT_WAVES 4
+#define PBD_DT_WAVES 1
 #endif
 constexpr int kDtWaves = PBD_DT_WAVES;   // waves per workgroup of the DT passes (each wave = 64 rows / columns)
 #ifndef PBD_DT_RING
