@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-exact-ref", action="store_true", help="skip the exact-mode reference run / agreement check")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
 
 
@@ -67,10 +69,15 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     model = synthetic_person_model()
     flat = model.flatten()
@@ -94,7 +101,8 @@ def main():
     def step():
         buf, n = det.detect_batch_device(d_frames.data_ptr(), B, rows, cols, cn, raw=True)
         if world > 1:
-            rec = pdist.gather_candidates(buf, n, stride, cap_g, frame_offset=rank * B, device=dev)
+            rec = pdist.gather_candidates(buf, n, stride, cap_g, frame_offset=rank * B,
+                                          device=dev if args.backend == "nccl" else "cpu")
             return len(rec)
         return n
 
@@ -117,7 +125,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = det.hd.profile_read() if not args.no_profile else {}
