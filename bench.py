@@ -12,11 +12,11 @@ is gathered on rank 0 with one RCCL all_gather (frames are sharded, weak scaling
 own batch).  Workload = BASELINE.json configs[2] (person model, batch of 64 640x480 frames, full path
 on one GPU).  Rank 0 prints ONE JSON line.
 
-Convolution mode: the default is the matrix-core kernel (PBD_CONV_MFMA: operands split into two bf16
-terms, fp32 accumulation), whose responses stay within the north-star tolerance (1e-4; ~1e-5 observed)
-and whose candidates are compared record by record with the bit-exact mode at the end of the run
-(`agreement`).  `--conv-mode exact` times the bit-identical VALU kernel instead; at N=1 its throughput is
-reported next to the default in `exact_mode`.
+Convolution mode: `value` is measured with the bit-exact kernel (PBD_CONV_EXACT: every response, score and
+index identical to the reference order).  At N=1 the same batch is then also timed with the matrix-core
+kernel (PBD_CONV_MFMA: operands split into two bf16 terms, fp32 accumulation; responses within the
+north-star tolerance of 1e-4) and reported as `fast_mode`, together with a record-by-record comparison of
+its candidates with the exact ones (`agreement`).  `--conv-mode mfma` makes that kernel the timed one.
 """
 import argparse
 import ctypes as C
@@ -45,11 +45,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
-    ap.add_argument("--conv-mode", choices=["exact", "fma", "mfma"], default="mfma")
+    ap.add_argument("--conv-mode", choices=["exact", "fma", "mfma"], default="exact")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the same workload timed on the host CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--no-exact-ref", action="store_true", help="skip the exact-mode reference run / agreement check")
+    ap.add_argument("--no-other-mode", "--no-exact-ref", dest="no_other", action="store_true",
+                    help="skip the run of the other convolution mode / the agreement check")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
@@ -208,26 +209,39 @@ def main():
             cdt = time.perf_counter() - t1
             cpu = {"value": round(nf / cdt, 4), "unit": "detections/s", "cores": oracle.num_threads(), "kind": "port",
                    "sample": f"{nf} of the same 640x480 frames, full path, OpenMP at the reference's 5 sites"}
-        exact_mode, agreement = None, None
-        if world == 1 and args.conv_mode != "exact" and not args.no_exact_ref:
+        other_mode, agreement = None, None
+        if world == 1 and args.conv_mode in ("exact", "mfma") and not args.no_other:
+            # the other convolution mode on the same resident batch: exact <-> matrix cores
+            oname = "mfma" if args.conv_mode == "exact" else "exact"
             last = np.array(det._buf[:ncand * stride]).reshape(ncand, stride).copy()
-            det2 = PartsBasedDetector(device=local_rank, conv_mode=_lib.CONV_EXACT, max_batch=B, max_candidates=cap)
+            det2 = PartsBasedDetector(device=local_rank, conv_mode=_lib.CONV_MFMA if oname == "mfma" else _lib.CONV_EXACT,
+                                      max_batch=B, max_candidates=cap)
             det2.distributeModel(model)
             buf2, n2 = det2.detect_batch_device(d_frames.data_ptr(), B, rows, cols, cn, raw=True)      # warm-up
             det2.hd.check(det2.hd.lib.pbd_synchronize(det2.hd.h))
             t1 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(3):
                 buf2, n2 = det2.detect_batch_device(d_frames.data_ptr(), B, rows, cols, cn, raw=True)
             det2.hd.check(det2.hd.lib.pbd_synchronize(det2.hd.h))
-            edt = (time.perf_counter() - t1) / 2
+            edt = (time.perf_counter() - t1) / 3
             ref = np.array(buf2[:n2 * stride]).reshape(n2, stride)
-            same = int(n2 == ncand and np.array_equal(ref[:, [0, 1, 2, 3, 4]], last[:, [0, 1, 2, 3, 4]]) and
-                       np.array_equal(ref[:, 6:], last[:, 6:]))
-            sdiff = float(np.abs(ref[:, 5].view(np.float32) - last[:, 5].view(np.float32)).max()) if same and n2 else None
-            exact_mode = {"value": round(B / edt, 3), "ms_per_step": round(edt * 1e3, 3), "conv_mode": "exact",
-                          "note": "bit-identical responses (reference summation order)"}
-            agreement = {"candidates_default": int(ncand), "candidates_exact": int(n2), "records_identical": bool(same),
-                         "max_score_diff": sdiff, "tolerance": 1e-4}
+            # record-by-record comparison keyed by (frame, component, level, root x, root y)
+            ka = {tuple(r[:5]): r for r in last}
+            kb = {tuple(r[:5]): r for r in ref}
+            common = set(ka) & set(kb)
+            boxes_same = sum(int(np.array_equal(ka[k][6:], kb[k][6:])) for k in common)
+            sdiff = max((abs(float(ka[k][5:6].view(np.float32)[0]) - float(kb[k][5:6].view(np.float32)[0])) for k in common), default=0.0)
+            odd = [r for k, r in list(ka.items()) + list(kb.items()) if k not in common]
+            # a root present in only one mode must sit within the score tolerance of the threshold
+            margin = max((abs(float(r[5:6].view(np.float32)[0]) - flat.thresh) for r in odd), default=0.0)
+            other_mode = {"conv_mode": oname, "value": round(B / edt, 3), "unit": "detections/s", "ms_per_step": round(edt * 1e3, 3),
+                          "note": ("matrix-core convolution (bf16 hi/lo operand split, fp32 accumulation): responses within 1e-4, "
+                                   "index outputs can differ on near ties (see agreement)") if oname == "mfma" else
+                                  "bit-identical responses (reference summation order)"}
+            agreement = {"candidates_exact": int(ncand if oname == "mfma" else n2), "candidates_mfma": int(n2 if oname == "mfma" else ncand),
+                         "common": len(common), "common_with_identical_parts": int(boxes_same), "only_in_one_mode": len(odd),
+                         "max_score_diff_common": sdiff, "max_threshold_margin_of_unmatched": margin, "tolerance": 1e-4,
+                         "records_identical": bool(len(odd) == 0 and boxes_same == len(common))}
             det2.hd.close()
         out = {
             "metric": "detections/sec (whole node), person model @640x480", "value": round(value, 3),
@@ -239,7 +253,8 @@ def main():
                        "frames_per_gpu_per_step": B, "conv_mode": args.conv_mode, "candidates_last_step": int(ncand),
                        "parallelism": f"frames sharded over {world} GPU(s), RCCL all_gather of candidates"},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": stage_ms,
-            "roofline_all": roof_all, "exact_mode": exact_mode, "agreement": agreement,
+            "roofline_all": roof_all,
+            ("fast_mode" if args.conv_mode == "exact" else "exact_mode"): other_mode, "agreement": agreement,
         }
         print(json.dumps(out), flush=True)
     det.hd.close()

@@ -11,17 +11,23 @@ import json
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-names = {"k_conv_mfma": "k_conv_mfma", "k_conv": "k_conv", "k_dt_rows": "k_dt_rows", "k_dt_cols": "k_dt_cols", "k_dp_combine": "k_dp_combine",
+names = {"k_conv_mfma<": "k_conv_mfma", "k_conv<": "k_conv", "k_dt_rows": "k_dt_rows", "k_dt_cols": "k_dt_cols", "k_dp_combine": "k_dp_combine",
          "k_hog_hist": "k_hog_hist", "k_hog_feat": "k_hog_feat", "k_resize": "k_resize", "k_pyrdown": "k_pyrdown", "k_dp_root": "k_dp_root"}
 acc = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
-for ctr in ("fetch", "write"):
-    f = max(glob.glob(f"gpurun_out/pmc_{ctr}_{tag}/*/*counter_collection.csv"), key=__import__("os").path.getmtime)
+import os
+import shutil
+for ctr, mode in (("fetch", "exact"), ("write", "exact"), ("fetch", "mfma"), ("write", "mfma")):
+    f = max(glob.glob(f"gpurun_out/pmc_{ctr}_{tag}_{mode}/*/*counter_collection.csv"), key=os.path.getmtime)
+    shutil.copy(f, f"profiles/{tag}_final_pmc_{ctr}_size_{mode}.csv")
     for r in csv.DictReader(open(f)):
-        for key in names:
-            if key + "<" in r["Kernel_Name"] or key + "(" in r["Kernel_Name"]:
+        if mode == "mfma" and "k_conv_mfma" not in r["Kernel_Name"]:
+            continue        # the other kernels are identical in both modes: take them from the exact run
+        for pat, key in names.items():
+            if (pat in r["Kernel_Name"]) if pat.endswith("<") else (pat + "<" in r["Kernel_Name"] or pat + "(" in r["Kernel_Name"]):
                 acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
                 if ctr == "fetch":
                     acc[key]["launches"] += 1
+                break
 out = {}
 for k, v in acc.items():
     out[k] = {"fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"], "launches_per_step": v["launches"],
@@ -29,3 +35,7 @@ for k, v in acc.items():
 json.dump(out, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"]):
     print(k, f"{v['hbm_bytes_per_step'] / 1e9:.2f} GB/step", v["launches_per_step"])
+
+for mode in ("exact", "mfma"):
+    f = max(glob.glob(f"gpurun_out/prof_{tag}_{mode}/*/*kernel_stats.csv"), key=os.path.getmtime)
+    shutil.copy(f, f"profiles/{tag}_final_kernel_stats_{mode}.csv")
