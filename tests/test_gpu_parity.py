@@ -344,3 +344,22 @@ def test_mfma_more_than_one_filter_block(det_mod, oracle):
     for f in (0, 31, 159, 160, 169):
         assert np.abs(got[f] - oracle.conv(feat, filters[f])).max() <= 1e-4
     hd.close()
+
+
+def test_no_candidates_and_alternating_sizes(det_mod, oracle):
+    """thresh above every root score -> empty list (not an error); frames of different sizes through one
+    handle (plan cache, grow-only workspace) give the same answers as fresh handles."""
+    model = M.synthetic_tiny_model(thresh=1e9)
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    assert det.detect(synth.synthetic_frame(1, 96, 128, 3)) == []
+    det.hd.close()
+    model = M.synthetic_tiny_model(thresh=0.8)
+    flat = model.flatten()
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    frames = [synth.synthetic_frame(3, 96, 128, 3), synth.synthetic_frame(4, 211, 173, 3), synth.synthetic_frame(5, 64, 300, 1),
+              synth.synthetic_frame(3, 96, 128, 3)]
+    for f in frames:
+        _compare_candidates(det.detect(f), oracle.detect(flat, f))
+    det.hd.close()
