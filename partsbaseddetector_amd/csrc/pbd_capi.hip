@@ -203,7 +203,7 @@ struct pbd_handle {
     bool have_features = false, have_resp = false, have_dp = false;
 
     // workspace
-    DevBuf frames, pyr, hist, norm, feat, resp, acc, Ix, Iy, Ik, rootv, rooti;
+    DevBuf frames, pyr, gmag, gori, hist, norm, feat, resp, acc, Ix, Iy, Ik, rootv, rooti;
     DevBuf tmp, dt, IxT, IxRaw, IyRaw, stk, cand, count, scales_tmp;
     std::vector<int32_t> cand_host;
 
@@ -648,6 +648,8 @@ int build_model(pbd_handle *h, const pbd_model *m)
 int alloc_features(pbd_handle *h, Plan &P, int nframes)
 {
     HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * P.cn));
+    HIPCHK(h, h->gmag.ensure((size_t)nframes * P.pix_per_frame * h->rs));
+    HIPCHK(h, h->gori.ensure((size_t)nframes * P.pix_per_frame));
     HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * h->rs));
     HIPCHK(h, h->norm.ensure((size_t)nframes * P.blk_per_frame * h->rs));
     HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * 32 * h->rs, 16)));
@@ -676,6 +678,7 @@ void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int f0, int n
     hp.lv = P.d_lv.d; hp.nlevels = P.nlevels; hp.cn = cn; hp.sbin = h->sbin; hp.frame0 = f0;
     hp.pix_per_frame = P.pix_per_frame; hp.blk_per_frame = P.blk_per_frame; hp.cell_per_frame = P.cell_per_frame;
     hp.pyr = h->pyr.as<uint8_t>(); hp.coord = h->d_coord.p;
+    hp.gmag = h->gmag.p; hp.gori = h->gori.as<uint8_t>();
     hp.hist = h->hist.p; hp.norm = h->norm.p; hp.feat = h->feat.p;
     {
         ProfScope ps(h, PBD_K_HOG_HIST, st);
@@ -985,7 +988,7 @@ void pbd_destroy(pbd_handle *h)
     h->prof.release();
     for (auto e : h->chunk_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    for (DevBuf *b : {&h->frames, &h->pyr, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
+    for (DevBuf *b : {&h->frames, &h->pyr, &h->gmag, &h->gori, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
                       &h->rooti, &h->tmp, &h->dt, &h->IxT, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();

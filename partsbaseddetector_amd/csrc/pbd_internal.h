@@ -102,6 +102,8 @@ struct HogParams {
     long long pix_per_frame, blk_per_frame, cell_per_frame;
     const uint8_t *pyr;
     const void *coord;            // HogCoordT<R>[]
+    void *gmag;                   // R [frames][pix_per_frame] gradient magnitude per image pixel
+    uint8_t *gori;                // [frames][pix_per_frame] snapped orientation 0..17
     void *hist;                   // R [frames][18][blk_per_frame]
     void *norm;                   // R [frames][blk_per_frame]
     void *feat;                   // R [frames][cell_per_frame*32]

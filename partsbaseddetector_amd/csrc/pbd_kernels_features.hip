@@ -117,29 +117,84 @@ template <typename R> __device__ __forceinline__ R real_sqrt(R v);
 template <> __device__ __forceinline__ float real_sqrt<float>(float v) { return sqrtf(v); }
 template <> __device__ __forceinline__ double real_sqrt<double>(double v) { return sqrt(v); }
 
+// Pass 1: per image pixel, the snapped orientation (0..17) and the gradient magnitude of the strongest
+// colour channel (src/HOGFeatures.cpp:205-260).  Every pixel feeds four blocks, so this part is done once
+// per pixel instead of once per (pixel, block).
+template <typename R>
+__global__ __launch_bounds__(256) void k_hog_grad(HogParams p)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.pix_per_frame) return;
+    const int frame = p.frame0 + blockIdx.y;
+    const int l = find_level<0>(p.lv, 0, p.nlevels, idx);
+    const LevelDesc d = p.lv[l];
+    const int local = (int)(idx - d.img_off);
+    const int rows = d.img_rows, cols = d.img_cols;
+    const int ys = local / cols, xs = local - ys * cols;
+    const size_t o = (size_t)frame * p.pix_per_frame + idx;
+    if (xs < 1 || ys < 1 || xs > cols - 2 || ys > rows - 2) return;     // never sampled (clamped to cols-2 / rows-2)
+    const int cn = p.cn;
+    const uint8_t *im = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off) * cn;
+    const size_t stride = (size_t)cols * cn;
+    const R uu[9] = {(R)1.000, (R)0.9397, (R)0.7660, (R)0.5000, (R)0.1736, (R)-0.1736, (R)-0.5000, (R)-0.7660, (R)-0.9397};
+    const R vv[9] = {(R)0.000, (R)0.3420, (R)0.6428, (R)0.8660, (R)0.9848, (R)0.9848, (R)0.8660, (R)0.6428, (R)0.3420};
+    R dx, dy, v;
+    if (cn == 1) {
+        const uint8_t *s = im + xs + (size_t)ys * stride;
+        dy = (R)((int)s[stride] - (int)*(s - stride));
+        dx = (R)((int)s[1] - (int)s[-1]);
+        v = dx * dx + dy * dy;
+    } else {
+        const uint8_t *s = im + 3 * xs + (size_t)ys * stride;
+        const R dyb = (R)((int)s[stride] - (int)*(s - stride));
+        const R dxb = (R)((int)s[3] - (int)s[-3]);
+        const R vb = dxb * dxb + dyb * dyb;
+        const R dyg = (R)((int)s[stride + 1] - (int)*(s - stride + 1));
+        const R dxg = (R)((int)s[4] - (int)s[-2]);
+        const R vg = dxg * dxg + dyg * dyg;
+        dy = (R)((int)s[stride + 2] - (int)*(s - stride + 2));
+        dx = (R)((int)s[5] - (int)s[-1]);
+        v = dx * dx + dy * dy;
+        if (vg > v) { v = vg; dx = dxg; dy = dyg; }
+        if (vb > v) { v = vb; dx = dxb; dy = dyb; }
+    }
+    R best_dot = (R)0;
+    int best_o = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const R dot = uu[k] * dx + vv[k] * dy;
+        if (dot > best_dot) { best_dot = dot; best_o = k; }
+        else if (-dot > best_dot) { best_dot = -dot; best_o = k + 9; }
+    }
+    static_cast<R *>(p.gmag)[o] = real_sqrt<R>(v);
+    p.gori[o] = (uint8_t)best_o;
+}
+
+// Pass 2: one thread per block walks its source pixels in raster order and adds (wy*wx)*mag into the bin
+// of the pixel's orientation.  The 18 bins of a thread live in LDS ([18][256], the thread always hits bank
+// tid % 32), so the update is one read-add-write instead of 18 predicated register adds; the sequence of
+// float additions per bin is the reference's.  Also writes the block energy (:270-283).
 template <typename R>
 __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.blk_per_frame) return;
+    __shared__ R bins[18 * 256];
+    const long long idx0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = idx0 < p.blk_per_frame;
+    const long long idx = active ? idx0 : p.blk_per_frame - 1;
     const int frame = p.frame0 + blockIdx.y;
     const int l = find_level<1>(p.lv, 0, p.nlevels, idx);
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.blk_off);
     const int by = local / d.blk_cols, bx = local - by * d.blk_cols;
-    const int cn = p.cn, sbin = p.sbin;
+    const int sbin = p.sbin;
     const int rows = d.img_rows, cols = d.img_cols;
     const int vish = d.blk_rows * sbin, visw = d.blk_cols * sbin;
-    const uint8_t *im = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off) * cn;
-    const size_t stride = (size_t)cols * cn;
+    const R *gmag = static_cast<const R *>(p.gmag) + (size_t)frame * p.pix_per_frame + d.img_off;
+    const uint8_t *gori = p.gori + (size_t)frame * p.pix_per_frame + d.img_off;
     const HogCoordT<R> *coord = static_cast<const HogCoordT<R> *>(p.coord);
-
-    const R uu[9] = {(R)1.000, (R)0.9397, (R)0.7660, (R)0.5000, (R)0.1736, (R)-0.1736, (R)-0.5000, (R)-0.7660, (R)-0.9397};
-    const R vv[9] = {(R)0.000, (R)0.3420, (R)0.6428, (R)0.8660, (R)0.9848, (R)0.9848, (R)0.8660, (R)0.6428, (R)0.3420};
-
-    R h[18];
+    R *h = bins + threadIdx.x;
 #pragma unroll
-    for (int o = 0; o < 18; ++o) h[o] = (R)0;
+    for (int o = 0; o < 18; ++o) h[o * 256] = (R)0;
 
     int ylo = sbin * by - sbin, yhi = sbin * by + 2 * sbin;
     int xlo = sbin * bx - sbin, xhi = sbin * bx + 2 * sbin;
@@ -147,6 +202,7 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
     if (xlo < 1) xlo = 1;
     if (yhi > vish - 1) yhi = vish - 1;
     if (xhi > visw - 1) xhi = visw - 1;
+    if (!active) yhi = ylo;
 
     for (int y = ylo; y < yhi; ++y) {
         const HogCoordT<R> cy = coord[y];
@@ -162,48 +218,22 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
             else if (cx.ip + 1 == bx) wx = cx.v0;
             else continue;
             const int xs = x < cols - 2 ? x : cols - 2;
-            R dx, dy, v;
-            if (cn == 1) {
-                const uint8_t *s = im + xs + (size_t)ys * stride;
-                dy = (R)((int)s[stride] - (int)*(s - stride));
-                dx = (R)((int)s[1] - (int)s[-1]);
-                v = dx * dx + dy * dy;
-            } else {
-                const uint8_t *s = im + 3 * xs + (size_t)ys * stride;
-                const R dyb = (R)((int)s[stride] - (int)*(s - stride));
-                const R dxb = (R)((int)s[3] - (int)s[-3]);
-                const R vb = dxb * dxb + dyb * dyb;
-                const R dyg = (R)((int)s[stride + 1] - (int)*(s - stride + 1));
-                const R dxg = (R)((int)s[4] - (int)s[-2]);
-                const R vg = dxg * dxg + dyg * dyg;
-                dy = (R)((int)s[stride + 2] - (int)*(s - stride + 2));
-                dx = (R)((int)s[5] - (int)s[-1]);
-                v = dx * dx + dy * dy;
-                if (vg > v) { v = vg; dx = dxg; dy = dyg; }
-                if (vb > v) { v = vb; dx = dxb; dy = dyb; }
-            }
-            R best_dot = (R)0;
-            int best_o = 0;
-#pragma unroll
-            for (int o = 0; o < 9; ++o) {
-                const R dot = uu[o] * dx + vv[o] * dy;
-                if (dot > best_dot) { best_dot = dot; best_o = o; }
-                else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
-            }
-            v = real_sqrt<R>(v);
+            const size_t g = (size_t)ys * cols + xs;
             // the four scatter lines multiply (vy?*vx?) first, then by v; products commute
-            const R contrib = (wy * wx) * v;
-#pragma unroll
-            for (int o = 0; o < 18; ++o) h[o] += (o == best_o) ? contrib : (R)0;
+            const R contrib = (wy * wx) * gmag[g];
+            R *bin = h + (int)gori[g] * 256;
+            *bin = *bin + contrib;
         }
     }
+    if (!active) return;
     R *hist = static_cast<R *>(p.hist) + (size_t)frame * 18 * p.blk_per_frame + idx;
+    R hv[18];
 #pragma unroll
-    for (int o = 0; o < 18; ++o) hist[(size_t)o * p.blk_per_frame] = h[o];
+    for (int o = 0; o < 18; ++o) { hv[o] = h[o * 256]; hist[(size_t)o * p.blk_per_frame] = hv[o]; }
     R e = (R)0;
 #pragma unroll
     for (int o = 0; o < 9; ++o) {
-        const R t = h[o] + h[o + 9];
+        const R t = hv[o] + hv[o + 9];
         e += t * t;
     }
     static_cast<R *>(p.norm)[(size_t)frame * p.blk_per_frame + idx] = e;
@@ -211,6 +241,9 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
 
 void launch_hog_hist(const HogParams &p, int nframes, bool f64, hipStream_t s)
 {
+    dim3 gridp((unsigned)((p.pix_per_frame + 255) / 256), nframes);
+    if (f64) hipLaunchKernelGGL(k_hog_grad<double>, gridp, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_hog_grad<float>, gridp, dim3(256), 0, s, p);
     dim3 grid((unsigned)((p.blk_per_frame + 255) / 256), nframes);
     if (f64) hipLaunchKernelGGL(k_hog_hist<double>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_hog_hist<float>, grid, dim3(256), 0, s, p);
