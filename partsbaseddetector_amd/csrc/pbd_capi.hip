@@ -108,14 +108,15 @@ struct Plan {
     DevTable<LevelDesc> d_lv;
     DevTable<ResizeTabX> d_tabx;
     DevTable<ResizeTabY> d_taby;
-    DevTable<ConvTile> d_tiles;
+    DevTable<ConvTile> d_tiles, d_shaped;
+    int nshaped[3] = {0, 0, 0};
     DevTable<int> d_row2level, d_rowoff, d_col2level, d_coloff;
     DevTable<long long> d_stk_row_off, d_stk_col_off;
     long long stk_per_jf = 0;
     DevTable<float> d_scales;
     void release()
     {
-        d_lv.release(); d_tabx.release(); d_taby.release(); d_tiles.release();
+        d_lv.release(); d_tabx.release(); d_taby.release(); d_tiles.release(); d_shaped.release();
         d_row2level.release(); d_rowoff.release(); d_col2level.release(); d_coloff.release(); d_scales.release();
         d_stk_row_off.release(); d_stk_col_off.release();
     }
@@ -243,11 +244,40 @@ struct ProfScope {
 };
 
 // ---- plan construction -------------------------------------------------------------------------
+// Cover a rows x cols level with 256-cell tiles of shape 32x8, 16x16 or 8x32 (shape k: 32>>k wide, 8<<k
+// high) so that the fewest lanes compute cells outside the level: a dynamic program over the columns picks
+// the vertical strips, each strip is then cut into tiles of its shape.
+static void cover_level(int l, int rows, int cols, std::vector<ConvTile> *shaped)
+{
+    const long long INF = 1LL << 60;
+    std::vector<long long> cost(cols + 1, INF);
+    std::vector<int> pick(cols + 1, -1);
+    cost[0] = 0;
+    for (int w = 1; w <= cols; ++w)
+        for (int k = 0; k < 3; ++k) {
+            const int tw = kConvTW >> k, th = kConvTH << k;
+            const int prev = std::max(w - tw, 0);
+            const long long c = cost[prev] + (long long)tw * ((rows + th - 1) / th) * th;
+            if (c < cost[w]) { cost[w] = c; pick[w] = k; }
+        }
+    std::vector<std::pair<int, int>> strips;   // (x0, shape), right to left
+    for (int w = cols; w > 0;) {
+        const int k = pick[w], tw = kConvTW >> k;
+        const int x0 = std::max(w - tw, 0);
+        strips.push_back({x0, k});
+        w = x0;
+    }
+    for (auto it = strips.rbegin(); it != strips.rend(); ++it) {
+        const int k = it->second, th = kConvTH << k;
+        for (int y0 = 0; y0 < rows; y0 += th) shaped[k].push_back({l, y0, it->first});
+    }
+}
+
 void finish_plan_tables(Plan &P)
 {
     // flat row / column lookup and conv tiles over the feature maps
     std::vector<int> row2level, rowoff(P.nlevels + 1, 0), col2level, coloff(P.nlevels + 1, 0);
-    std::vector<ConvTile> tiles;
+    std::vector<ConvTile> tiles, shaped[3];
     for (int l = 0; l < P.nlevels; ++l) {
         const LevelDesc &d = P.lv[l];
         rowoff[l] = (int)row2level.size();
@@ -257,6 +287,7 @@ void finish_plan_tables(Plan &P)
             for (int x = 0; x < d.cols; ++x) col2level.push_back(l);
             for (int y0 = 0; y0 < d.rows; y0 += kConvTH)
                 for (int x0 = 0; x0 < d.cols; x0 += kConvTW) tiles.push_back({l, y0, x0});
+            cover_level(l, d.rows, d.cols, shaped);
         }
     }
     rowoff[P.nlevels] = (int)row2level.size();
@@ -285,6 +316,9 @@ void finish_plan_tables(Plan &P)
     (void)P.d_stk_col_off.upload(scol);
     (void)P.d_lv.upload(P.lv);
     (void)P.d_tiles.upload(tiles);
+    std::vector<ConvTile> all;
+    for (int k = 0; k < 3; ++k) { P.nshaped[k] = (int)shaped[k].size(); all.insert(all.end(), shaped[k].begin(), shaped[k].end()); }
+    (void)P.d_shaped.upload(all);
     (void)P.d_row2level.upload(row2level);
     (void)P.d_rowoff.upload(rowoff);
     (void)P.d_col2level.upload(col2level);
@@ -701,6 +735,8 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
 {
     ConvParams cp{};
     cp.lv = P.d_lv.d; cp.tiles = P.d_tiles.d; cp.ntiles = P.ntiles;
+    cp.shaped = P.d_shaped.d;
+    for (int k = 0; k < 3; ++k) cp.nshaped[k] = P.nshaped[k];
     cp.F = h->F; cp.Fpad = h->Fpad; cp.ksize = h->ksize; cp.frame0 = f0;
     const int ngroups = h->Fpad / kConvQ;
     // few workgroups (single frame): split the filter groups over more workgroups to fill the chip

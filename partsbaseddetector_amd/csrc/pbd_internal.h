@@ -111,8 +111,10 @@ struct HogParams {
 
 struct ConvParams {
     const LevelDesc *lv;
-    const ConvTile *tiles;
+    const ConvTile *tiles;        // uniform 32 x 8 tiling (generic and MFMA kernels)
     int ntiles;
+    const ConvTile *shaped;       // mixed-shape tiling of the exact 5x5 kernel: 32x8 tiles, then 16x16, then 8x32
+    int nshaped[3];
     int F, Fpad, ksize;
     int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
     int frame0;

@@ -8,7 +8,8 @@
 // the sign of an intermediate zero, which cannot reach the response: it starts at +0 and x + (+-0)
 // == x).  FMA mode fuses multiply and add (scores within 1e-4, not bit-identical).
 //
-// Mapping: one workgroup = one 32 x 8 tile of one level of one frame.  The (32+k-1) x (8+k-1) x 32
+// Mapping: one workgroup = one 256-cell tile (32 x 8, 16 x 16 or 8 x 32: the host covers each level with
+// the mix that wastes the fewest lanes) of one level of one frame.  The (TW+k-1) x (TH+k-1) x 32
 // channel input tile is staged once in LDS, re-laid out channel-planar so that a wave's lanes
 // (consecutive x) read consecutive LDS words; out-of-image cells are materialised with the
 // reference's constant border (0, but 1 for the last channel: :147-156).  Each thread owns one
@@ -27,27 +28,27 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const v4f __attribute__((address_space(4))) cfloat4;
 
-// K x K filters, NW waves per workgroup.  Every wave covers the whole 32 x 8 tile: lane = (x, half),
-// 4 consecutive rows per lane, whose 8 x K input window of one channel sits in registers; the waves
+// K x K filters, NW waves per workgroup, tile shape S (TW = 32 >> S wide, TH = 8 << S high).  Every wave
+// covers the whole tile: lane = (x, row group), 4 consecutive rows per lane, whose 8 x K input window of one channel sits in registers; the waves
 // split the filter groups (wave w takes groups w, w+NW, ...).
 // Weights: the K*K*8 weights of a (group, channel) are 800 contiguous bytes in HBM ([g][c][tap][8]).
 // Each wave stages them into its own double-buffered LDS slice with one 16-byte load per lane, one
 // channel ahead of use, and reads them back with broadcast ds_read_b128 (all lanes, same address), so
 // the inner loop has no scalar-cache traffic and LDS waits can be counted (lgkmcnt(N)).
 // Per (channel, tap): 2 broadcast LDS reads and 32 multiply-adds per lane (16 packed mul + 16 packed add).
-template <int K, bool FMA, int NW>
-__global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p, const float *__restrict__ wts, const float *__restrict__ featp,
-                                                  float *__restrict__ respp)
+template <int K, bool FMA, int NW, int S>
+__device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__restrict__ wts, const float *__restrict__ featp,
+                                          float *__restrict__ respp, float *sm, const ConvTile tile)
 {
-    constexpr int TW = kConvTW, TH = kConvTH, Q = kConvQ, P = 4;
+    constexpr int TW = kConvTW >> S, TH = kConvTH << S, Q = kConvQ, P = 4;
+    static_assert(TW * TH == 256 && TH % P == 0, "a wave of 64 lanes x 4 rows covers the tile");
     constexpr int PW = TW + K - 1, PH = TH + K - 1;
     constexpr int PLANE = (PH * PW) | 1;   // odd plane stride: conflict-free staging writes
     constexpr int WCH = K * K * Q;         // weights of one (group, channel)
     constexpr int WLANES = (WCH + 3) / 4;  // lanes that stage 16 bytes each
     static_assert(WLANES <= 64, "one staging instruction per wave");
-    __shared__ __attribute__((aligned(16))) float sm[32 * PLANE + 3 + NW * 2 * WLANES * 4];
+    static_assert(32 * PLANE + 3 + NW * 2 * WLANES * 4 <= 32 * 433 + 3 + NW * 2 * WLANES * 4, "LDS sized for the largest shape");
 
-    const ConvTile tile = p.tiles[blockIdx.x];
     const int frame = p.frame0 + blockIdx.z;
     const LevelDesc d = p.lv[tile.level];
     const int H = d.rows, W = d.cols;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p
 
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int px = lane & 31, py = (lane >> 5) * P;
+    const int px = lane & (TW - 1), py = (lane >> (5 - S)) * P;
     const int x = tile.x0 + px, y = tile.y0 + py;
     const int ngroups = p.Fpad / Q;
     const int g0 = blockIdx.y * p.groups_per_block;
@@ -154,6 +155,19 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p
             }
         }
     }
+}
+
+// one launch covers all three tile shapes: the shape is uniform per workgroup (tiles are sorted by shape)
+template <int K, bool FMA, int NW>
+__global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p, const float *__restrict__ wts, const float *__restrict__ featp,
+                                                  float *__restrict__ respp)
+{
+    __shared__ __attribute__((aligned(16))) float sm[32 * 433 + 3 + NW * 2 * ((K * K * kConvQ + 3) / 4) * 4];
+    const int b = blockIdx.x;
+    const ConvTile tile = p.shaped[b];
+    if (b < p.nshaped[0]) conv_tile<K, FMA, NW, 0>(p, wts, featp, respp, sm, tile);
+    else if (b < p.nshaped[0] + p.nshaped[1]) conv_tile<K, FMA, NW, 1>(p, wts, featp, respp, sm, tile);
+    else conv_tile<K, FMA, NW, 2>(p, wts, featp, respp, sm, tile);
 }
 
 // generic kernel: any filter size, any real type R (the reference's T=double instantiation runs here);
@@ -247,6 +261,14 @@ static void launch_generic(const ConvParams &p, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((k_conv_generic<R, FMA>), grid, dim3(256), lds, s, p);
 }
 
+template <bool FMA, int NW>
+static void launch_shapes(const ConvParams &p, int gy, int nframes, hipStream_t s)
+{
+    const int nt = p.nshaped[0] + p.nshaped[1] + p.nshaped[2];
+    hipLaunchKernelGGL((k_conv<5, FMA, NW>), dim3(nt, gy, nframes), dim3(NW * 64), 0, s, p, static_cast<const float *>(p.wts),
+                       static_cast<const float *>(p.feat), static_cast<float *>(p.resp));
+}
+
 void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.ntiles == 0 || p.F == 0) return;
@@ -257,17 +279,9 @@ void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s)
         // waves per workgroup: prefer a count that divides the groups of a workgroup evenly
         const int gb = std::min(p.groups_per_block, ngroups);
         const int nw = (gb % 5 == 0) ? 5 : (gb % 6 == 0) ? 6 : (gb % 4 == 0) ? 4 : 5;
-        const float *w = static_cast<const float *>(p.wts), *ft = static_cast<const float *>(p.feat);
-        float *rp = static_cast<float *>(p.resp);
-#define PBD_LAUNCH_CONV(NW)                                                                            \
-    do {                                                                                               \
-        if (p.fma) hipLaunchKernelGGL((k_conv<5, true, NW>), grid, dim3(NW * 64), 0, s, p, w, ft, rp);  \
-        else hipLaunchKernelGGL((k_conv<5, false, NW>), grid, dim3(NW * 64), 0, s, p, w, ft, rp);       \
-    } while (0)
-        if (nw == 5) PBD_LAUNCH_CONV(5);
-        else if (nw == 6) PBD_LAUNCH_CONV(6);
-        else PBD_LAUNCH_CONV(4);
-#undef PBD_LAUNCH_CONV
+        if (nw == 5) { if (p.fma) launch_shapes<true, 5>(p, gy, nframes, s); else launch_shapes<false, 5>(p, gy, nframes, s); }
+        else if (nw == 6) { if (p.fma) launch_shapes<true, 6>(p, gy, nframes, s); else launch_shapes<false, 6>(p, gy, nframes, s); }
+        else { if (p.fma) launch_shapes<true, 4>(p, gy, nframes, s); else launch_shapes<false, 4>(p, gy, nframes, s); }
     } else if (f64) {
         if (p.fma) launch_generic<double, true>(p, grid, s); else launch_generic<double, false>(p, grid, s);
     } else {
