@@ -19,6 +19,7 @@
 #include "pbd_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace pbd {
 
@@ -30,7 +31,7 @@ typedef const v4f __attribute__((address_space(4))) cfloat4;
 
 // K x K filters, NW waves per workgroup, tile shape S (TW = 32 >> S wide, TH = 8 << S high).  Every wave
 // covers the whole tile: lane = (x, row group), 4 consecutive rows per lane, whose 8 x K input window of one channel sits in registers; the waves
-// split the filter groups (wave w takes groups w, w+NW, ...).
+// share the filter groups (handed out through an LDS counter).
 // Weights: the K*K*8 weights of a (group, channel) are 800 contiguous bytes in HBM ([g][c][tap][8]).
 // Each wave stages them into its own double-buffered LDS slice with one 16-byte load per lane, one
 // channel ahead of use, and reads them back with broadcast ds_read_b128 (all lanes, same address), so
@@ -38,7 +39,7 @@ typedef const v4f __attribute__((address_space(4))) cfloat4;
 // Per (channel, tap): 2 broadcast LDS reads and 32 multiply-adds per lane (16 packed mul + 16 packed add).
 template <int K, bool FMA, int NW, int S>
 __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__restrict__ wts, const float *__restrict__ featp,
-                                          float *__restrict__ respp, float *sm, const ConvTile tile)
+                                          float *__restrict__ respp, float *sm, int *next_g, const ConvTile tile)
 {
     constexpr int TW = kConvTW >> S, TH = kConvTH << S, Q = kConvQ, P = 4;
     static_assert(TW * TH == 256 && TH % P == 0, "a wave of 64 lanes x 4 rows covers the tile");
@@ -67,6 +68,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
             sm[c * PLANE + ci] = v;
         }
     }
+    const int g0 = blockIdx.y * p.groups_per_block;
+    if (t == 0) *next_g = g0;
     __syncthreads();
 
     const int lane = t & 63;
@@ -74,7 +77,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
     const int px = lane & (TW - 1), py = (lane >> (5 - S)) * P;
     const int x = tile.x0 + px, y = tile.y0 + py;
     const int ngroups = p.Fpad / Q;
-    const int g0 = blockIdx.y * p.groups_per_block;
     const int g1 = min(g0 + p.groups_per_block, ngroups);
     const size_t HW = (size_t)H * W;
     float *resp = respp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)y * W + x;
@@ -83,7 +85,13 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
     float *wbuf = sm + ((32 * PLANE + 3) & ~3) + wave * (2 * WLANES * 4);
     const bool wl = lane < WLANES;
 
-    for (int g = g0 + wave; g < g1; g += NW) {
+    // filter groups are handed out dynamically: the 2 x NW waves of the resident workgroups do not spread
+    // evenly over the 4 SIMDs, so waves on the less loaded SIMDs take more groups
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(next_g, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= g1) break;
         const v4f *wsrc = reinterpret_cast<const v4f *>(wts + (size_t)g * 32 * WCH) + lane;
         v4f wreg = wl ? wsrc[0] : v4f{0.f, 0.f, 0.f, 0.f};
         if (wl) *reinterpret_cast<v4f *>(wbuf + lane * 4) = wreg;
@@ -163,11 +171,12 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p
                                                   float *__restrict__ respp)
 {
     __shared__ __attribute__((aligned(16))) float sm[32 * 433 + 3 + NW * 2 * ((K * K * kConvQ + 3) / 4) * 4];
+    __shared__ int next_g;
     const int b = blockIdx.x;
     const ConvTile tile = p.shaped[b];
-    if (b < p.nshaped[0]) conv_tile<K, FMA, NW, 0>(p, wts, featp, respp, sm, tile);
-    else if (b < p.nshaped[0] + p.nshaped[1]) conv_tile<K, FMA, NW, 1>(p, wts, featp, respp, sm, tile);
-    else conv_tile<K, FMA, NW, 2>(p, wts, featp, respp, sm, tile);
+    if (b < p.nshaped[0]) conv_tile<K, FMA, NW, 0>(p, wts, featp, respp, sm, &next_g, tile);
+    else if (b < p.nshaped[0] + p.nshaped[1]) conv_tile<K, FMA, NW, 1>(p, wts, featp, respp, sm, &next_g, tile);
+    else conv_tile<K, FMA, NW, 2>(p, wts, featp, respp, sm, &next_g, tile);
 }
 
 // generic kernel: any filter size, any real type R (the reference's T=double instantiation runs here);
@@ -276,9 +285,10 @@ void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s)
     const int gy = (ngroups + p.groups_per_block - 1) / p.groups_per_block;
     dim3 grid(p.ntiles, gy, nframes);
     if (!f64 && p.ksize == 5) {
-        // waves per workgroup: prefer a count that divides the groups of a workgroup evenly
-        const int gb = std::min(p.groups_per_block, ngroups);
-        const int nw = (gb % 5 == 0) ? 5 : (gb % 6 == 0) ? 6 : (gb % 4 == 0) ? 4 : 5;
+        // waves per workgroup: 4, so that the two resident workgroups put 2 waves on every SIMD (5 or 6 leave
+        // the SIMDs unevenly loaded: 54.7 / 50.9 ms vs 46.0 ms per 64-frame step); PBD_CONV_NW overrides for experiments
+        int nw = 4;
+        if (const char *e = getenv("PBD_CONV_NW")) nw = atoi(e);
         if (nw == 5) { if (p.fma) launch_shapes<true, 5>(p, gy, nframes, s); else launch_shapes<false, 5>(p, gy, nframes, s); }
         else if (nw == 6) { if (p.fma) launch_shapes<true, 6>(p, gy, nframes, s); else launch_shapes<false, 6>(p, gy, nframes, s); }
         else { if (p.fma) launch_shapes<true, 4>(p, gy, nframes, s); else launch_shapes<false, 4>(p, gy, nframes, s); }
