@@ -775,7 +775,7 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
     HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
-    HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * sizeof(int), 16)));
+    HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkEntryF64 : kStkEntryF32), 16)));
@@ -791,7 +791,7 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     dp.resp = h->resp.p; dp.acc = h->acc.p;
     dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;
-    dp.IxT = h->IxT.as<int>(); dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
+    dp.IxT = h->IxT.as<int16_t>(); dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
     dp.stk = h->stk.p; dp.stk_per_jf = P.stk_per_jf;
     dp.stk_row_off = P.d_stk_row_off.d; dp.stk_col_off = P.d_stk_col_off.d;
     dp.biasw = h->d_biasw.d;

@@ -138,7 +138,7 @@ struct DpParams {
     // group scratch, indexed by chunk-local frame
     int JG;                       // jobs in this group
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
-    int *IxT;                     // rows-pass pointers, transposed [x][y]
+    int16_t *IxT;                 // rows-pass pointers, transposed [x][y]
     int16_t *IxRaw, *IyRaw;       // row-major pointers written by the columns pass
     void *stk;                    // [chunk][JG][stk_per_jf] 12-byte entries, wave-private, lane-interleaved
     long long stk_per_jf;         // entries per (job, frame)

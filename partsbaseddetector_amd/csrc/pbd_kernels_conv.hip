@@ -21,6 +21,10 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef PBD_CONV_UNROLL_ROWS
+#define PBD_CONV_UNROLL_ROWS 0
+#endif
+
 namespace pbd {
 
 // Weights are read-only for the whole launch and every address is wave-uniform: reading them
@@ -113,7 +117,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
             for (int pp = 0; pp < P; ++pp)
 #pragma unroll
                 for (int q = 0; q < Q / 2; ++q) s[pp][q] = v2f{0.0f, 0.0f};
+#if PBD_CONV_UNROLL_ROWS
+#pragma unroll
+#else
 #pragma clang loop unroll(disable)
+#endif
             for (int i = 0; i < K; ++i) {
                 float fw[P][K];
 #pragma unroll

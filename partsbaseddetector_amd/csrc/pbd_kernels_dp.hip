@@ -156,7 +156,8 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
 }
 
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef short v8s_u __attribute__((ext_vector_type(8), aligned(2)));
+static_assert(kDtCH % 8 == 0, "the columns pass reads its int16 pointers 8 at a time");
 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
 template <typename R>
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const int Hl = d.rows;
     const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y;
     R *tmpT = static_cast<R *>(p.tmp) + obase;
-    int *ixT = p.IxT + obase;
+    int16_t *ixT = p.IxT + obase;
     __shared__ R ring_z[kDtWaves * kDtT * 64], ring_s[kDtWaves * kDtT * 64];
     __shared__ int ring_v[kDtWaves * kDtT * 64];
     const int ro = (threadIdx.x >> 6) * (kDtT * 64) + lane;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     auto store = [&](int q0, const R *out, const int *ptr, const int *) {
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i)
-            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = ptr[i]; }
+            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (int16_t)ptr[i]; }
     };
     auto noaux = [](int, int *) {};
     dt_stream<R, false>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
     const DtJob job = p.jobs[j];
     const size_t jbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
     const R *tmpT = static_cast<const R *>(p.tmp) + jbase + (size_t)x * H;     // this lane's column, contiguous
-    const int *ixT = p.IxT + jbase + (size_t)x * H;
+    const int16_t *ixT = p.IxT + jbase + (size_t)x * H;
     R *dt = static_cast<R *>(p.dt) + jbase + x;
     int16_t *iyr = p.IyRaw + jbase + x;
     int16_t *ixr = p.IxRaw + jbase + x;
@@ -264,9 +265,10 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
     auto aux = [&](int q0, int *buf) {      // the rows pass's pointers of this column
         if (q0 + kDtCH <= H) {
 #pragma unroll
-            for (int v = 0; v < kDtCH / 4; ++v) {
-                const v4i_u a0 = *reinterpret_cast<const v4i_u *>(ixT + q0 + 4 * v);
-                buf[4 * v] = a0.x; buf[4 * v + 1] = a0.y; buf[4 * v + 2] = a0.z; buf[4 * v + 3] = a0.w;
+            for (int v = 0; v < kDtCH / 8; ++v) {
+                const v8s_u a0 = *reinterpret_cast<const v8s_u *>(ixT + q0 + 8 * v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) buf[8 * v + e] = a0[e];
             }
         } else {
 #pragma unroll
