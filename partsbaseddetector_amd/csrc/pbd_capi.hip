@@ -100,7 +100,7 @@ struct Plan {
     int nlevels = 0;
     std::vector<LevelDesc> lv;
     std::vector<float> scales;
-    long long pix_per_frame = 0, blk_per_frame = 0, cell_per_frame = 0, npix_resized = 0;
+    long long pix_per_frame = 0, blk_per_frame = 0, cell_per_frame = 0, npix_resized = 0, quad_per_frame = 0;
     int interval = 0;
     int nrows_flat = 0, ncols_flat = 0;
     int ntiles = 0;
@@ -278,7 +278,10 @@ void finish_plan_tables(Plan &P)
     // flat row / column lookup and conv tiles over the feature maps
     std::vector<int> row2level, rowoff(P.nlevels + 1, 0), col2level, coloff(P.nlevels + 1, 0);
     std::vector<ConvTile> tiles, shaped[3];
+    P.quad_per_frame = 0;
     for (int l = 0; l < P.nlevels; ++l) {
+        P.lv[l].quad_off = P.quad_per_frame;
+        P.quad_per_frame += ((long long)P.lv[l].rows * P.lv[l].cols + 3) / 4;
         const LevelDesc &d = P.lv[l];
         rowoff[l] = (int)row2level.size();
         coloff[l] = (int)col2level.size();
@@ -787,7 +790,7 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
 {
     DpParams dp{};
     dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC; dp.NM = h->NM;
-    dp.cell_per_frame = P.cell_per_frame;
+    dp.cell_per_frame = P.cell_per_frame; dp.quad_per_frame = P.quad_per_frame;
     dp.resp = h->resp.p; dp.acc = h->acc.p;
     dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;

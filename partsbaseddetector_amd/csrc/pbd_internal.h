@@ -23,6 +23,7 @@ struct LevelDesc {
     long long img_off;        // pixel offset of the level image (multiply by channels for bytes)
     long long blk_off;        // block offset
     long long cell_off;       // cell offset
+    long long quad_off;       // offset in units of 4 consecutive cells of a level (combine step)
 };
 
 // resize tables (cv::resize INTER_LINEAR 8U fixed point)
@@ -138,6 +139,7 @@ struct DpParams {
     // group scratch, indexed by chunk-local frame
     int JG;                       // jobs in this group
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
+    long long quad_per_frame;
     int16_t *IxT;                 // rows-pass pointers, transposed [x][y]
     int16_t *IxRaw, *IyRaw;       // row-major pointers written by the columns pass
     void *stk;                    // [chunk][JG][stk_per_jf] 12-byte entries, wave-private, lane-interleaved

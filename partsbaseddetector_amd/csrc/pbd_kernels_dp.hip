@@ -296,84 +296,153 @@ void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
     else hipLaunchKernelGGL(k_dt_cols<float>, grid, dim3(64 * kDtWaves), 0, s, p);
 }
 
-// ---- combine: thread = cell of one PARENT part (block.y) ---------------------------------------------
+// ---- combine: thread = 4 consecutive cells of one level, one PARENT part (block.y) ---------------------
 // For every parent mixture m: acc = response(parent, m); then for each child in descending index order
 //   weighted[mm] = score_dt[child][mm] + bias(mm)[m]; reduceMax (strict >, first wins, start -inf; K==1 copies);
 //   Ix/Iy picked from the winning mixture with the reference's composition Iy[y][x] = IyRaw[y][Ix[y][x]]
 //   (include/DistanceTransform.hpp:233-244); acc += max   (src/DynamicProgram.cpp:134-156).
 // The accumulated plane is the input of the parent's own distance transform in the next group.
-template <typename R>
+// Four cells per thread: every plane is read and written with 16 / 8 / 4-byte accesses per lane.
+template <typename T, int N> struct CellVec;
+#define PBD_CELLVEC(T, E, N) template <> struct CellVec<T, N> { typedef E type __attribute__((ext_vector_type(N), aligned(sizeof(E)))); }
+PBD_CELLVEC(float, float, 4); PBD_CELLVEC(float, float, 2); PBD_CELLVEC(double, double, 4); PBD_CELLVEC(double, double, 2);
+PBD_CELLVEC(int16_t, short, 4); PBD_CELLVEC(int16_t, short, 2); PBD_CELLVEC(uint8_t, unsigned char, 4); PBD_CELLVEC(uint8_t, unsigned char, 2);
+#undef PBD_CELLVEC
+
+template <typename T, int kCpt>
+__device__ __forceinline__ void load_cells(const T *src, int n, T *dst)
+{   // n valid cells (1..kCpt); unaligned wide access is fine in global memory
+    if (n == kCpt) {
+        const typename CellVec<T, kCpt>::type v = *reinterpret_cast<const typename CellVec<T, kCpt>::type *>(src);
+#pragma unroll
+        for (int e = 0; e < kCpt; ++e) dst[e] = (T)v[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < kCpt; ++e) dst[e] = (e < n) ? src[e] : (T)0;
+    }
+}
+template <typename T, int kCpt>
+__device__ __forceinline__ void store_cells(T *dst, int n, const T *src)
+{
+    if (n == kCpt) {
+        typename CellVec<T, kCpt>::type v;
+#pragma unroll
+        for (int e = 0; e < kCpt; ++e) v[e] = src[e];
+        *reinterpret_cast<typename CellVec<T, kCpt>::type *>(dst) = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < kCpt; ++e) if (e < n) dst[e] = src[e];
+    }
+}
+
+template <typename R, int kCpt>
 __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.cell_per_frame) return;
+    constexpr int SUB = 4 / kCpt;   // threads per group of 4 cells
+    const long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long qidx = gidx / SUB;
+    if (qidx >= p.quad_per_frame) return;
     const int fl = blockIdx.z, frame = p.frame0 + fl;
     const CombineJob cj = p.cjobs[blockIdx.y];
     int lo = 0, hi = p.nlevels;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (p.lv[mid].cell_off <= idx) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (p.lv[mid].quad_off <= qidx) lo = mid; else hi = mid; }
     const LevelDesc d = p.lv[lo];
-    const int local = (int)(idx - d.cell_off);
     const int W = d.cols;
-    const size_t HW = (size_t)d.rows * W;
-    const int y = local / W;
-    const R *resp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
+    const int HWi = d.rows * W;
+    const size_t HW = (size_t)HWi;
+    const int local = (int)(qidx - d.quad_off) * 4 + (int)(gidx % SUB) * kCpt;
+    if (local >= HWi) return;
+    const int n = min(kCpt, HWi - local);
+    int rowbase[kCpt];       // y * W of each cell
+#pragma unroll
+    for (int e = 0; e < kCpt; ++e) rowbase[e] = ((local + e) / W) * W;
+    const R *resp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + local;
     const R *dtp = static_cast<const R *>(p.dt);
     const size_t gbase0 = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG;
     const size_t pbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + local;
-    R accv[kMaxMix];
+    R accv[kMaxMix][kCpt];
 #pragma unroll
-    for (int pm = 0; pm < kMaxMix; ++pm) accv[pm] = (pm < cj.npar) ? resp[(size_t)cj.filter[pm] * HW + local] : (R)0;
+    for (int pm = 0; pm < kMaxMix; ++pm) {
+#pragma unroll
+        for (int e = 0; e < kCpt; ++e) accv[pm][e] = (R)0;
+        if (pm < cj.npar) load_cells<R, kCpt>(resp + (size_t)cj.filter[pm] * HW, n, accv[pm]);
+    }
+    // the job tables and biases are read-only and wave-uniform: reading them through the constant address
+    // space keeps them on the scalar unit (a plain global load after the first store would be a vector load
+    // the compiler has to wait for at every use)
+    const int __attribute__((address_space(4))) *childs = (const int __attribute__((address_space(4))) *)p.childs;
+    static_assert(sizeof(ChildDesc) == 11 * sizeof(int), "ChildDesc is read as 11 ints");
+    const float __attribute__((address_space(4))) *biasw = (const float __attribute__((address_space(4))) *)p.biasw;
     for (int ch = cj.child_begin; ch < cj.child_end; ++ch) {
-        const ChildDesc cd = p.childs[ch];
+        ChildDesc cd;
+        {
+            const int __attribute__((address_space(4))) *ci = childs + (size_t)ch * 11;
+            cd.job_begin = ci[0]; cd.nmix = ci[1]; cd.slot = ci[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cd.bias_off[k] = ci[3 + k];
+        }
         const size_t gbase = gbase0 + (size_t)cd.job_begin * HW;
-        R dtv[kMaxMix];
-        int ixv[kMaxMix];
+        float bw[kMaxMix][kMaxMix]; // bias(mm)[pm]
+#pragma unroll
+        for (int mm = 0; mm < kMaxMix; ++mm)
+#pragma unroll
+            for (int pm = 0; pm < kMaxMix; ++pm)
+                bw[mm][pm] = (mm < cd.nmix && pm < cj.npar) ? biasw[cd.bias_off[mm] + pm] : 0.0f;
+        R dtv[kMaxMix][kCpt];
+        int16_t ixv[kMaxMix][kCpt];
 #pragma unroll
         for (int mm = 0; mm < kMaxMix; ++mm) {
-            dtv[mm] = (R)0; ixv[mm] = 0;
+#pragma unroll
+            for (int e = 0; e < kCpt; ++e) { dtv[mm][e] = (R)0; ixv[mm][e] = 0; }
             if (mm < cd.nmix) {
-                dtv[mm] = dtp[gbase + (size_t)mm * HW + local];
-                ixv[mm] = p.IxRaw[gbase + (size_t)mm * HW + local];
+                load_cells<R, kCpt>(dtp + gbase + (size_t)mm * HW + local, n, dtv[mm]);
+                load_cells<int16_t, kCpt>(p.IxRaw + gbase + (size_t)mm * HW + local, n, ixv[mm]);
             }
         }
 #pragma unroll
         for (int pm = 0; pm < kMaxMix; ++pm) {
             if (pm < cj.npar) {
-                R best;
-                int bi = 0, ix = ixv[0];
-                if (cd.nmix == 1) {
-                    best = dtv[0] + (R)p.biasw[cd.bias_off[0] + pm];
-                } else {
-                    best = -RealLimits<R>::inf();
+                int16_t oix[kCpt], oiy[kCpt];
+                uint8_t oik[kCpt];
 #pragma unroll
-                    for (int mm = 0; mm < kMaxMix; ++mm) {
-                        if (mm < cd.nmix) {
-                            const R wv = dtv[mm] + (R)p.biasw[cd.bias_off[mm] + pm];
-                            if (wv > best) { bi = mm; best = wv; ix = ixv[mm]; }
+                for (int e = 0; e < kCpt; ++e) {
+                    R best;
+                    int bi = 0, ix = ixv[0][e];
+                    if (cd.nmix == 1) {
+                        best = dtv[0][e] + (R)bw[0][pm];
+                    } else {
+                        best = -RealLimits<R>::inf();
+#pragma unroll
+                        for (int mm = 0; mm < kMaxMix; ++mm) {
+                            if (mm < cd.nmix) {
+                                const R wv = dtv[mm][e] + (R)bw[mm][pm];
+                                if (wv > best) { bi = mm; best = wv; ix = ixv[mm][e]; }
+                            }
                         }
                     }
+                    int iy = 0;
+                    if (e < n) iy = p.IyRaw[gbase + (size_t)bi * HW + rowbase[e] + ix];
+                    oix[e] = (int16_t)ix; oiy[e] = (int16_t)iy; oik[e] = (uint8_t)bi;
+                    accv[pm][e] = accv[pm][e] + best;
                 }
-                const int iy = p.IyRaw[gbase + (size_t)bi * HW + (size_t)y * W + ix];
                 const size_t o = pbase + (size_t)(cd.slot + pm) * HW;
-                p.Ix[o] = (int16_t)ix;
-                p.Iy[o] = (int16_t)iy;
-                p.Ik[o] = (uint8_t)bi;
-                accv[pm] = accv[pm] + best;
+                store_cells<int16_t, kCpt>(p.Ix + o, n, oix);
+                store_cells<int16_t, kCpt>(p.Iy + o, n, oiy);
+                store_cells<uint8_t, kCpt>(p.Ik + o, n, oik);
             }
         }
     }
     R *acc = static_cast<R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM + local;
 #pragma unroll
     for (int pm = 0; pm < kMaxMix; ++pm)
-        if (pm < cj.npar) acc[(size_t)(cj.acc_plane + pm) * HW] = accv[pm];
+        if (pm < cj.npar) store_cells<R, kCpt>(acc + (size_t)(cj.acc_plane + pm) * HW, n, accv[pm]);
 }
 
 void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hipStream_t s)
 {
-    if (ncjobs == 0 || p.cell_per_frame == 0) return;
-    dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), ncjobs, nframes);
-    if (f64) hipLaunchKernelGGL(k_dp_combine<double>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_dp_combine<float>, grid, dim3(256), 0, s, p);
+    if (ncjobs == 0 || p.quad_per_frame == 0) return;
+    if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2>), dim3((unsigned)((p.quad_per_frame * 2 + 255) / 256), ncjobs, nframes), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_dp_combine<float, 4>), dim3((unsigned)((p.quad_per_frame + 255) / 256), ncjobs, nframes), dim3(256), 0, s, p);
 }
 
 // ---- root: rootv = max over root mixtures of (accumulated score + bias) ----------------------------
