@@ -78,10 +78,12 @@ struct DtRing {
     }
     __device__ __forceinline__ void pop(int idx, R &zk, R &sk, int &vk)
     {   // entry `idx` becomes the top
-        if (idx >= lo) {
-            const int slot = idx & (kDtT - 1);
-            zk = z[slot * 64]; sk = s[slot * 64]; vk = v[slot * 64];
-        } else {
+        // the ring slot is read unconditionally (always a valid LDS address) so that the common case is three
+        // plain ds_read_b32; only a pop below the ring overrides it from the spill stack
+        const int slot = idx & (kDtT - 1);
+        zk = z[slot * 64]; sk = s[slot * 64]; vk = v[slot * 64];
+        asm volatile("" : "+v"(zk), "+v"(sk), "+v"(vk));   // keep these as LDS reads (not a flat load of a selected pointer)
+        if (idx < lo) {
             const StkEntryT<R> e = g[(size_t)idx * 64];
             zk = e.z; sk = e.s; vk = e.v;
             lo = idx;
