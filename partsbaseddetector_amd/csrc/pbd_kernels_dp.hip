@@ -62,32 +62,45 @@ constexpr int kDtWaves = PBD_DT_WAVES;   // waves per workgroup of the DT passes
 #endif
 constexpr int kDtT = PBD_DT_RING;    // ring entries per lane (power of two)
 
+// LDS layout of a wave's ring: [slot][z: 64 x R | s: 64 x R | v: 64 x int]; one address per lane, the rest
+// are immediate offsets.
 template <typename R>
 struct DtRing {
-    R *z; R *s; int *v;           // this lane's column of the [T][64] arrays
+    static constexpr int kSlotBytes = 64 * (2 * (int)sizeof(R) + 4);
+    char *zs;                     // this lane's z of slot 0 (s is 64 R further)
+    char *vp;                     // this lane's v of slot 0
     StkEntryT<R> *g;              // this lane's column of the global [k][lane] stack
     int lo;                       // ring holds indices [lo, top)
+    __device__ __forceinline__ R &z(int slot) { return *reinterpret_cast<R *>(zs + slot * kSlotBytes); }
+    __device__ __forceinline__ R &s(int slot) { return *reinterpret_cast<R *>(zs + slot * kSlotBytes + 64 * (int)sizeof(R)); }
+    __device__ __forceinline__ int &v(int slot) { return *reinterpret_cast<int *>(vp + slot * kSlotBytes); }
     __device__ __forceinline__ void push_below(int idx, R zk, R sk, int vk)
     {   // entry `idx` (the old top) moves under a new top
         const int slot = idx & (kDtT - 1);
         if (idx - lo >= kDtT) {   // slot still holds live entry idx - T: spill it
-            g[(size_t)(idx - kDtT) * 64] = StkEntryT<R>{z[slot * 64], s[slot * 64], v[slot * 64]};
+            g[(size_t)(idx - kDtT) * 64] = StkEntryT<R>{z(slot), s(slot), v(slot)};
             lo = idx - kDtT + 1;
         }
-        z[slot * 64] = zk; s[slot * 64] = sk; v[slot * 64] = vk;
+        z(slot) = zk; s(slot) = sk; v(slot) = vk;
     }
     __device__ __forceinline__ void pop(int idx, R &zk, R &sk, int &vk)
     {   // entry `idx` becomes the top
-        // the ring slot is read unconditionally (always a valid LDS address) so that the common case is three
-        // plain ds_read_b32; only a pop below the ring overrides it from the spill stack
+        // the ring slot is read unconditionally (always a valid LDS address) so that the common case is
+        // plain LDS reads; only a pop below the ring overrides it from the spill stack
         const int slot = idx & (kDtT - 1);
-        zk = z[slot * 64]; sk = s[slot * 64]; vk = v[slot * 64];
+        zk = z(slot); sk = s(slot); vk = v(slot);
         asm volatile("" : "+v"(zk), "+v"(sk), "+v"(vk));   // keep these as LDS reads (not a flat load of a selected pointer)
         if (idx < lo) {
             const StkEntryT<R> e = g[(size_t)idx * 64];
             zk = e.z; sk = e.s; vk = e.v;
             lo = idx;
         }
+    }
+    // the ring of wave `w` of the workgroup inside `smem`
+    static __device__ __forceinline__ DtRing make(char *smem, int w, int lane, StkEntryT<R> *g)
+    {
+        char *base = smem + (size_t)w * kDtT * kSlotBytes;
+        return DtRing{base + lane * (int)sizeof(R), base + 128 * (int)sizeof(R) + lane * 4, g, 0};
     }
 };
 
@@ -186,12 +199,10 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y;
     R *tmpT = static_cast<R *>(p.tmp) + obase;
     int16_t *ixT = p.IxT + obase;
-    __shared__ R ring_z[kDtWaves * kDtT * 64], ring_s[kDtWaves * kDtT * 64];
-    __shared__ int ring_v[kDtWaves * kDtT * 64];
-    const int ro = (threadIdx.x >> 6) * (kDtT * 64) + lane;
-    DtRing<R> ring{ring_z + ro, ring_s + ro, ring_v + ro,
-                   reinterpret_cast<StkEntryT<R> *>(p.stk) +
-                       ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane, 0};
+    __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
+    DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
+                                     reinterpret_cast<StkEntryT<R> *>(p.stk) +
+                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane);
     const int N = active ? W : 0;
     if (N == 0) return;
     auto load = [&](int q0, R *buf) {
@@ -245,12 +256,10 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
     R *dt = static_cast<R *>(p.dt) + jbase + x;
     int16_t *iyr = p.IyRaw + jbase + x;
     int16_t *ixr = p.IxRaw + jbase + x;
-    __shared__ R ring_z[kDtWaves * kDtT * 64], ring_s[kDtWaves * kDtT * 64];
-    __shared__ int ring_v[kDtWaves * kDtT * 64];
-    const int ro = (threadIdx.x >> 6) * (kDtT * 64) + lane;
-    DtRing<R> ring{ring_z + ro, ring_s + ro, ring_v + ro,
-                   reinterpret_cast<StkEntryT<R> *>(p.stk) +
-                       ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane, 0};
+    __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
+    DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
+                                     reinterpret_cast<StkEntryT<R> *>(p.stk) +
+                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane);
     auto load = [&](int q0, R *buf) {
         if (sizeof(R) == 4 && q0 + kDtCH <= H) {
             const float *srcf = reinterpret_cast<const float *>(tmpT);
