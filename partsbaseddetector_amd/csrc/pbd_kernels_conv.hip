@@ -61,15 +61,31 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
     const int t = threadIdx.x;
     const float *feat = featp + ((size_t)frame * p.cell_per_frame + d.cell_off) * 32;
 
-    {   // stage: lane = channel, NW*2 cells per pass; global reads are 128-byte cells
-        const int c = t & 31;
-        const float border = (c == 31) ? 1.0f : 0.0f;
-        for (int ci = t >> 5; ci < PH * PW; ci += NW * 2) {
-            const int cy = ci / PW, cx = ci - cy * PW;
-            const int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
-            float v = border;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = feat[((size_t)gy * W + gx) * 32 + c];
-            sm[c * PLANE + ci] = v;
+    {   // stage: 8 lanes read the 128-byte cell of a position as 4 channels each, NW*8 cells per pass, in
+        // batches of UB independent loads; each lane then scatters its 4 channels to their planes
+        // (bank = 4*c4 + cell + 17*k mod 32: two lanes per bank, the minimum for 64 lanes)
+        constexpr int CPP = NW * 8, NIT = (PH * PW + CPP - 1) / CPP, UB = 7;
+        const int c4 = t & 7, cell0 = t >> 3;
+        const v4f border = (c4 == 7) ? v4f{0.0f, 0.0f, 0.0f, 1.0f} : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it0 = 0; it0 < NIT; it0 += UB) {
+            v4f v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int ci = (it0 + u) * CPP + cell0;
+                const int cy = ci / PW, cx = ci - cy * PW;
+                const int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
+                v[u] = border;
+                if (it0 + u < NIT && ci < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    v[u] = *reinterpret_cast<const v4f *>(feat + ((size_t)gy * W + gx) * 32 + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int ci = (it0 + u) * CPP + cell0;
+                if (it0 + u < NIT && ci < PH * PW) {
+                    float *dst = sm + (c4 * 4) * PLANE + ci;
+                    dst[0] = v[u].x; dst[PLANE] = v[u].y; dst[2 * PLANE] = v[u].z; dst[3 * PLANE] = v[u].w;
+                }
+            }
         }
     }
     const int g0 = blockIdx.y * p.groups_per_block;
@@ -158,7 +174,18 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
                 for (int q = 0; q < Q / 2; ++q) r[pp][q] = r[pp][q] + s[pp][q];
             if (c + 1 < 32 && wl) *reinterpret_cast<v4f *>(wbuf + ((c + 1) & 1) * (WLANES * 4) + lane * 4) = wreg;
         }
-        if (x < W) {
+        // a full group (all but possibly the last) stores without per-filter branches: one block of 8
+        // independent stores per row
+        if (g * Q + Q <= p.F) {
+            float *rg = resp + (size_t)(g * Q) * HW;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                if (x < W && y + pp < H) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) rg[(size_t)q * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
+                }
+            }
+        } else if (x < W) {
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
                 if (y + pp < H) {
