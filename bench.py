@@ -153,8 +153,8 @@ def main():
         comb += sum(8 * nmix(g) for g in parents)           # per parent: response in, accumulated score out
         work = {
             "k_conv": {"bytes": (128 * cells + 4 * F * ktaps + 4 * F * cells) * B, "flop": 2.0 * ktaps * F * cells * B},
-            "k_dt_rows": {"bytes": 12 * cells * jobs * B},      # read score 4, write tmp 4 + Ix 4
-            "k_dt_cols": {"bytes": 16 * cells * jobs * B},      # read tmp 4 + Ix 4, write dt 4 + Iy 2 + Ix 2
+            "k_dt_rows": {"bytes": 10 * cells * jobs * B},      # read score 4, write tmp 4 + Ix 2
+            "k_dt_cols": {"bytes": 14 * cells * jobs * B},      # read tmp 4 + Ix 2, write dt 4 + Iy 2 + Ix 2
             "k_dp_combine": {"bytes": comb * cells * B},        # per child: dt/Ix in, Ix/Iy/Ik out; per parent: score in/out
             "k_hog_hist": {"bytes": (3 * int(np.sum(plan["img_rows"].astype(np.int64) * plan["img_cols"])) + 76 * cells) * B},
         }

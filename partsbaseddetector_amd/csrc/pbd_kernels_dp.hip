@@ -178,12 +178,14 @@ static_assert(kDtCH % 8 == 0, "the columns pass reads its int16 pointers 8 at a 
 template <typename R>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
-    const int wv = blockIdx.x * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
+    // the large levels are dispatched first and the tail of the launch is made of short ones
+    const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wv * 64 >= p.nrows_flat) return;
     const int r = wv * 64 + lane;
     const bool active = r < p.nrows_flat;
     const int rr = active ? r : p.nrows_flat - 1;
-    const int j = blockIdx.y, fl = blockIdx.z, frame = p.frame0 + fl;
+    const int j = blockIdx.x, fl = blockIdx.y, frame = p.frame0 + fl;
     const int l = p.row2level[rr];
     const LevelDesc d = p.lv[l];
     const int y = rr - p.rowoff[l];
@@ -231,7 +233,7 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.JG == 0 || p.nrows_flat == 0) return;
     const int nwv = (p.nrows_flat + 63) / 64;
-    dim3 grid((nwv + kDtWaves - 1) / kDtWaves, p.JG, nframes);
+    dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
     if (f64) hipLaunchKernelGGL(k_dt_rows<double>, grid, dim3(64 * kDtWaves), 0, s, p);
     else hipLaunchKernelGGL(k_dt_rows<float>, grid, dim3(64 * kDtWaves), 0, s, p);
 }
@@ -240,10 +242,10 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
 template <typename R>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
 {
-    const int wv = blockIdx.x * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // longest columns first, as in the rows pass
     const int cidx = wv * 64 + lane;
     if (cidx >= p.ncols_flat) return;
-    const int j = blockIdx.y, fl = blockIdx.z;
+    const int j = blockIdx.x, fl = blockIdx.y;
     const int l = p.col2level[cidx];
     const LevelDesc d = p.lv[l];
     const int x = cidx - p.coloff[l];
@@ -302,7 +304,7 @@ void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.JG == 0 || p.ncols_flat == 0) return;
     const int nwv = (p.ncols_flat + 63) / 64;
-    dim3 grid((nwv + kDtWaves - 1) / kDtWaves, p.JG, nframes);
+    dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
     if (f64) hipLaunchKernelGGL(k_dt_cols<double>, grid, dim3(64 * kDtWaves), 0, s, p);
     else hipLaunchKernelGGL(k_dt_cols<float>, grid, dim3(64 * kDtWaves), 0, s, p);
 }
