@@ -196,8 +196,10 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
 #pragma unroll
     for (int o = 0; o < 18; ++o) h[o * 256] = (R)0;
 
-    int ylo = sbin * by - sbin, yhi = sbin * by + 2 * sbin;
-    int xlo = sbin * bx - sbin, xhi = sbin * bx + 2 * sbin;
+    // pixels with ip in {b-1, b}: (y+0.5)/sbin - 0.5 in [b-1, b+1), i.e. y in [sbin*b - sbin/2 - 0.5, sbin*b + 3*sbin/2 - 0.5);
+    // one extra pixel either side, the table test below decides
+    int ylo = sbin * by - (sbin + 1) / 2 - 1, yhi = sbin * by + (3 * sbin + 1) / 2 + 1;
+    int xlo = sbin * bx - (sbin + 1) / 2 - 1, xhi = sbin * bx + (3 * sbin + 1) / 2 + 1;
     if (ylo < 1) ylo = 1;
     if (xlo < 1) xlo = 1;
     if (yhi > vish - 1) yhi = vish - 1;
