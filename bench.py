@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
-    ap.add_argument("--conv-mode", choices=["exact", "fma", "mfma"], default="exact")
+    ap.add_argument("--conv-mode", choices=["exact", "fma", "mfma", "mfma_f16"], default="exact")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the same workload timed on the host CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
@@ -84,7 +84,7 @@ def main():
     flat = model.flatten()
     B, rows, cols, cn = args.batch, args.rows, args.cols, 3
     cap = 1 << 16
-    det = PartsBasedDetector(device=local_rank, conv_mode={"exact": _lib.CONV_EXACT, "fma": _lib.CONV_FMA, "mfma": _lib.CONV_MFMA}[args.conv_mode],
+    det = PartsBasedDetector(device=local_rank, conv_mode={"exact": _lib.CONV_EXACT, "fma": _lib.CONV_FMA, "mfma": _lib.CONV_MFMA, "mfma_f16": _lib.CONV_MFMA_F16}[args.conv_mode],
                              max_batch=B, max_candidates=cap)
     det.distributeModel(model)
     stride = det.hd.stride
@@ -178,7 +178,7 @@ def main():
                      "algorithmic_bytes_per_launch": int(by), "traffic": (tr / per_step) if tr else None}
             if k == "k_conv":
                 fl = work[k]["flop"] / per_step
-                mfma = args.conv_mode == "mfma"
+                mfma = args.conv_mode in ("mfma", "mfma_f16")
                 peak = PEAK_BF16_TFLOPS if mfma else PEAK_F32_TFLOPS
                 ach = fl / avg_s / 1e12
                 entry.update({"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

@@ -71,13 +71,15 @@ typedef struct pbd_model {
 enum { PBD_REAL_F32 = 0, PBD_REAL_F64 = 1 };
 enum { PBD_CONV_EXACT = 0,   /* multiply and add rounded separately in the reference's order: bit-identical responses */
        PBD_CONV_FMA = 1,     /* fused multiply-add: responses within 1e-4, not bit-identical */
-       PBD_CONV_MFMA = 2 };  /* matrix cores, bf16 hi/lo operand split (3 MFMAs per product tile), fp32 accumulation:
+       PBD_CONV_MFMA = 2,    /* matrix cores, bf16 hi/lo operand split (3 MFMAs per product tile), fp32 accumulation:
                                 responses within 1e-4 (~1e-6 observed), not bit-identical; 5x5 filters, PBD_REAL_F32 only */
+       PBD_CONV_MFMA_F16 = 3 }; /* matrix cores, operands rounded once to fp16 (1 MFMA per product tile), fp32 accumulation:
+                                the 1e-4 bar does not hold (~1e-3 observed on unit-scale scores); same restrictions */
 
 typedef struct pbd_config {
     int device;            /* HIP device ordinal */
     int real_type;         /* PBD_REAL_F32 (src/demo.cpp:85) or PBD_REAL_F64 (cells/detect.cpp:93) */
-    int conv_mode;         /* PBD_CONV_EXACT / PBD_CONV_FMA / PBD_CONV_MFMA */
+    int conv_mode;         /* PBD_CONV_EXACT / PBD_CONV_FMA / PBD_CONV_MFMA / PBD_CONV_MFMA_F16 */
     int max_batch;         /* frames per pbd_detect_batch* call (>= 1) */
     int max_candidates;    /* candidate capacity per batch */
     void *stream;          /* hipStream_t to run on (NULL: the library creates its own) */

@@ -17,7 +17,7 @@ PBD_OK = 0
 STATUS = {0: "PBD_OK", -1: "PBD_ERR_INVALID", -2: "PBD_ERR_UNSUPPORTED", -3: "PBD_ERR_HIP", -4: "PBD_ERR_CAPACITY",
           -5: "PBD_ERR_STATE", -6: "PBD_ERR_NOMEM"}
 REAL_F32, REAL_F64 = 0, 1
-CONV_EXACT, CONV_FMA, CONV_MFMA = 0, 1, 2
+CONV_EXACT, CONV_FMA, CONV_MFMA, CONV_MFMA_F16 = 0, 1, 2, 3
 STAGE_FEATURES, STAGE_RESPONSES, STAGE_ROOTV, STAGE_ROOTI = 0, 1, 2, 3
 KERNELS = ["k_resize", "k_pyrdown", "k_hog_hist", "k_hog_feat", "k_conv", "k_dt_rows", "k_dt_cols", "k_dp_combine",
            "k_dp_root", "k_argmin"]

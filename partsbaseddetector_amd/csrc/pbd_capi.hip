@@ -477,9 +477,11 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
     }
     HIPCHK(h, h->d_wts.ensure(w.size() * sizeof(R)));
     HIPCHK(h, hipMemcpy(h->d_wts.p, w.data(), w.size() * sizeof(R), hipMemcpyHostToDevice));
-    if (h->cfg.conv_mode == PBD_CONV_MFMA) {
-        if (!fast) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA needs 5x5 filters and PBD_REAL_F32");
-        // records [pass][tap][160 filters][hi 32 bf16 | lo 32 bf16 | 8 pad], x = hi + lo with round-to-nearest-even
+    if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16) {
+        if (!fast) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA / PBD_CONV_MFMA_F16 need 5x5 filters and PBD_REAL_F32");
+        const bool f16 = h->cfg.conv_mode == PBD_CONV_MFMA_F16;
+        // records [pass][tap][160 filters][hi 32 bf16 | lo 32 bf16 | 8 pad], x = hi + lo with round-to-nearest-even;
+        // fp16 mode: [pass][tap][160 filters][32 fp16 | 8 pad]
         auto f2bf = [](float f) -> uint16_t {
             uint32_t u; memcpy(&u, &f, 4);
             if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
@@ -487,14 +489,32 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
             return (uint16_t)(u >> 16);
         };
         auto bf2f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+        auto f2h = [](float f) -> uint16_t {      // IEEE binary16, round to nearest even (what v_cvt_f16_f32 does)
+            uint32_t u; memcpy(&u, &f, 4);
+            const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+            const uint32_t ax = u & 0x7fffffffu;
+            if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
+            if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                // rounds to >= 65520: inf
+            if (ax < 0x33000001u) return sign;                                       // below half the smallest subnormal: 0
+            const int e = (int)(ax >> 23) - 127;
+            uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+            int shift = e >= -14 ? 13 : 13 + (-14 - e);                              // bits dropped from the 24-bit significand
+            const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
+            uint32_t q = m >> shift;
+            if (rest > half || (rest == half && (q & 1u))) ++q;
+            const uint32_t bits = e >= -14 ? (((uint32_t)(e + 15) << 10) + (q - 0x400u)) : q;   // carry propagates into the exponent
+            return (uint16_t)(sign | bits);
+        };
+        const int recw = (f16 ? kMfmaRecBytesF16 : kMfmaRecBytes) / 2;
         const int passes = (nfilters + kMfmaFilterBlock - 1) / kMfmaFilterBlock;
-        std::vector<uint16_t> rec((size_t)passes * K * K * kMfmaFilterBlock * (kMfmaRecBytes / 2), 0);
+        std::vector<uint16_t> rec((size_t)passes * K * K * kMfmaFilterBlock * recw, 0);
         for (int f = 0; f < nfilters; ++f) {
             const float *src = reinterpret_cast<const float *>(filters[f]);
             for (int t = 0; t < K * K; ++t) {
-                uint16_t *r = &rec[(((size_t)(f / kMfmaFilterBlock) * K * K + t) * kMfmaFilterBlock + f % kMfmaFilterBlock) * (kMfmaRecBytes / 2)];
+                uint16_t *r = &rec[(((size_t)(f / kMfmaFilterBlock) * K * K + t) * kMfmaFilterBlock + f % kMfmaFilterBlock) * recw];
                 for (int c = 0; c < 32; ++c) {
                     const float v = src[(size_t)t * 32 + c];
+                    if (f16) { r[c] = f2h(v); continue; }
                     const uint16_t hi = f2bf(v);
                     r[c] = hi;
                     r[32 + c] = f2bf(v - bf2f(hi));
@@ -749,7 +769,8 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     cp.feat = h->feat.p; cp.wts = h->d_wts.p; cp.resp = h->resp.p;
     cp.fma = h->cfg.conv_mode == PBD_CONV_FMA;
     ProfScope ps(h, PBD_K_CONV, st);
-    if (h->cfg.conv_mode == PBD_CONV_MFMA) launch_conv_mfma(cp, h->d_wrec.p, nb, st);
+    if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16)
+        launch_conv_mfma(cp, h->d_wrec.p, h->cfg.conv_mode == PBD_CONV_MFMA_F16, nb, st);
     else launch_conv(cp, nb, h->f64, st);
 }
 

@@ -182,8 +182,9 @@ void launch_hog_feat(const HogParams &p, int nframes, bool f64, hipStream_t s);
 void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s);
 int conv_occupancy(int nw);
 // matrix-core path (pbd_kernels_conv_mfma.hip); wrec: [pass][tap][160 filters][144 B] bf16 hi/lo records
-void launch_conv_mfma(const ConvParams &p, const void *wrec, int nframes, hipStream_t s);
-constexpr int kMfmaFilterBlock = 160, kMfmaRecBytes = 144;
+// PBD_CONV_MFMA_F16: 80 B fp16 records, one MFMA per product tile
+void launch_conv_mfma(const ConvParams &p, const void *wrec, bool f16, int nframes, hipStream_t s);
+constexpr int kMfmaFilterBlock = 160, kMfmaRecBytes = 144, kMfmaRecBytesF16 = 80;
 void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s);
 void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s);
 void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hipStream_t s);

@@ -363,3 +363,49 @@ def test_no_candidates_and_alternating_sizes(det_mod, oracle):
     for f in frames:
         _compare_candidates(det.detect(f), oracle.detect(flat, f))
     det.hd.close()
+
+
+def test_mfma_f16_mode(det_mod, oracle):
+    """PBD_CONV_MFMA_F16 (BASELINE.json configs[4] / SURVEY.md 8(d) config 5): operands rounded once to fp16, one
+    MFMA per product tile, fp32 accumulation.  The 1e-4 score bar does not apply; checked instead:
+      * against the reference-order convolution of the SAME fp16-rounded operands (numpy float16 rounding):
+        only the fp32 summation order differs -> 2e-5;
+      * against the unrounded reference: max-abs error reported, bounded by 5e-3;
+      * detections vs the exact path on the person model: agreement rate reported, root set overlap >= 90 %."""
+    from partsbaseddetector_amd import _lib
+    flat = M.synthetic_tiny_model().flatten()
+    hd = _handle(det_mod, flat, conv_mode=_lib.CONV_MFMA_F16)
+    conv = det_mod.SpatialConvolutionEngine(hd)
+    rng = np.random.default_rng(5)
+    filters = [rng.standard_normal((5, 5 * 32)).astype(np.float32) * 0.05 for _ in range(170)]   # two filter blocks
+    filters[3][2, 7] = 1e-7      # fp16 subnormal range
+    filters[4][1, 9] = 3e-9      # below half the smallest subnormal -> 0
+    conv.setFilters(filters)
+    feat = rng.random((19, 37 * 32), dtype=np.float32) * 0.4
+    got = conv.pdf([feat])[0]
+    f16 = lambda a: a.astype(np.float16).astype(np.float32)
+    worst_same, worst_ref = 0.0, 0.0
+    for f in (0, 3, 4, 31, 159, 160, 169):
+        worst_same = max(worst_same, float(np.abs(got[f] - oracle.conv(f16(feat), f16(filters[f]))).max()))
+        worst_ref = max(worst_ref, float(np.abs(got[f] - oracle.conv(feat, filters[f])).max()))
+    print(f"fp16 mode: max |resp - reference(fp16 operands)| = {worst_same:.3g}, max |resp - reference| = {worst_ref:.3g}")
+    assert worst_same <= 2e-5, worst_same
+    assert worst_ref <= 5e-3, worst_ref
+    hd.close()
+
+    model = M.synthetic_person_model(thresh=17.9)
+    im = synth.synthetic_frame(21, 160, 120, 3)
+    res = {}
+    for name, mode in (("exact", _lib.CONV_EXACT), ("f16", _lib.CONV_MFMA_F16)):
+        det = det_mod.PartsBasedDetector(device=0, conv_mode=mode)
+        det.distributeModel(model)
+        res[name] = {(c.level, c.component, c.root[1], c.root[0]): c for c in det.detect(im)}
+        det.hd.close()
+    common = set(res["exact"]) & set(res["f16"])
+    same_parts = sum(np.array_equal(res["exact"][k].parts, res["f16"][k].parts) for k in common)
+    dscore = max((abs(res["exact"][k].score() - res["f16"][k].score()) for k in common), default=0.0)
+    print(f"fp16 mode detections: exact {len(res['exact'])}, fp16 {len(res['f16'])}, common roots {len(common)}, "
+          f"identical part placements {same_parts}, max score diff {dscore:.3g}")
+    assert len(res["exact"]) > 0
+    assert len(common) >= 0.9 * max(len(res["exact"]), len(res["f16"]))
+    assert dscore <= 5e-2
