@@ -19,7 +19,6 @@
 #include "pbd_internal.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 #ifndef PBD_CONV_UNROLL_ROWS
 #define PBD_CONV_UNROLL_ROWS 0
@@ -157,14 +156,30 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
                 for (int j = 0; j < K; ++j) {
                     const v2f w[Q / 2] = {__builtin_shufflevector(wa[j], wa[j], 0, 1), __builtin_shufflevector(wa[j], wa[j], 2, 3),
                                           __builtin_shufflevector(wb[j], wb[j], 0, 1), __builtin_shufflevector(wb[j], wb[j], 2, 3)};
+                    if (FMA) {
 #pragma unroll
-                    for (int pp = 0; pp < P; ++pp) {
-                        const v2f f = v2f{fw[pp][j], fw[pp][j]};
+                        for (int pp = 0; pp < P; ++pp) {
+                            const v2f f = v2f{fw[pp][j], fw[pp][j]};
 #pragma unroll
-                        for (int q = 0; q < Q / 2; ++q) {
-                            if (FMA) s[pp][q] = __builtin_elementwise_fma(w[q], f, s[pp][q]);
-                            else s[pp][q] = s[pp][q] + w[q] * f;
+                            for (int q = 0; q < Q / 2; ++q) s[pp][q] = __builtin_elementwise_fma(w[q], f, s[pp][q]);
                         }
+                    } else {
+                        // the 16 products of a tap first, then the 16 additions: a product is 16 instructions old
+                        // when its addition issues, so the two waves of a SIMD never wait on VALU latency
+                        // (back-to-back mul -> add pairs through one temporary left the VALU 71 % busy)
+                        v2f t[P][Q / 2];
+#pragma unroll
+                        for (int pp = 0; pp < P; ++pp) {
+                            const v2f f = v2f{fw[pp][j], fw[pp][j]};
+#pragma unroll
+                            for (int q = 0; q < Q / 2; ++q) t[pp][q] = w[q] * f;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                            for (int q = 0; q < Q / 2; ++q) s[pp][q] = s[pp][q] + t[pp][q];
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -290,9 +305,7 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
 int conv_occupancy(int nw)
 {   // resident workgroups per CU of the exact 5x5 kernel (diagnostics)
     int n = -1;
-    if (nw == 5) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv<5, false, 5>, 320, 0);
     if (nw == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv<5, false, 4>, 256, 0);
-    if (nw == 6) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv<5, false, 6>, 384, 0);
     return n;
 }
 
@@ -320,13 +333,9 @@ void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s)
     const int gy = (ngroups + p.groups_per_block - 1) / p.groups_per_block;
     dim3 grid(p.ntiles, gy, nframes);
     if (!f64 && p.ksize == 5) {
-        // waves per workgroup: 4, so that the two resident workgroups put 2 waves on every SIMD (5 or 6 leave
-        // the SIMDs unevenly loaded: 54.7 / 50.9 ms vs 46.0 ms per 64-frame step); PBD_CONV_NW overrides for experiments
-        int nw = 4;
-        if (const char *e = getenv("PBD_CONV_NW")) nw = atoi(e);
-        if (nw == 5) { if (p.fma) launch_shapes<true, 5>(p, gy, nframes, s); else launch_shapes<false, 5>(p, gy, nframes, s); }
-        else if (nw == 6) { if (p.fma) launch_shapes<true, 6>(p, gy, nframes, s); else launch_shapes<false, 6>(p, gy, nframes, s); }
-        else { if (p.fma) launch_shapes<true, 4>(p, gy, nframes, s); else launch_shapes<false, 4>(p, gy, nframes, s); }
+        // 4 waves per workgroup, so that the two resident workgroups put 2 waves on every SIMD (5 or 6 leave the
+        // SIMDs unevenly loaded: 54.7 / 50.9 ms vs 46.0 ms per 64-frame step when this was measured)
+        if (p.fma) launch_shapes<true, 4>(p, gy, nframes, s); else launch_shapes<false, 4>(p, gy, nframes, s);
     } else if (f64) {
         if (p.fma) launch_generic<double, true>(p, grid, s); else launch_generic<double, false>(p, grid, s);
     } else {
