@@ -20,10 +20,6 @@
 
 #include <algorithm>
 
-#ifndef PBD_CONV_UNROLL_ROWS
-#define PBD_CONV_UNROLL_ROWS 0
-#endif
-
 namespace pbd {
 
 // Weights are read-only for the whole launch and every address is wave-uniform: reading them
@@ -119,76 +115,104 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
         for (int pp = 0; pp < P; ++pp)
 #pragma unroll
             for (int q = 0; q < Q / 2; ++q) r[pp][q] = v2f{0.0f, 0.0f};
-        for (int c = 0; c < 32; ++c) {
-            if (c + 1 < 32 && wl) wreg = wsrc[(size_t)(c + 1) * (WCH / 4)];   // next channel's weights, in flight during compute
-            const float *sp = sp0 + c * PLANE;
-            const float *wcur = wbuf + (c & 1) * (WLANES * 4);
-            // s = delta (0); s += kf[k]*src[k] over the taps in raster order (src/filter.cpp:3916-3922).
-            // Packed pairs of filters: one v_pk_mul_f32 + one v_pk_add_f32 per (pixel, filter pair), each
-            // half rounded separately exactly like the scalar sequence.  The tap-row loop is kept rolled
-            // so that only one row of weights (5 taps x 8) and one 4 x 5 input window are live at a time.
-            v2f s[P][Q / 2];
+        // Software-pipelined sliding window.  A lane's 4 output rows see input rows 0..7 of the tile column; tap
+        // row i uses rows i..i+3.  Every input row is read from LDS ONCE per channel, and the LDS reads of a stage
+        // (one new row of this channel, one row of the next channel's first four, the 5 x 8 weights of the next
+        // tap row: 15 instructions) are issued before the 160 packed operations of the stage, into registers the
+        // stage does not touch -- a wave never waits for its own LDS reads.  Two channels per loop iteration keep
+        // the buffer parity static (weights: 10 stages A B A B A | B A B A B; rows: even / odd channel).
+        float Ft[P + K - 1][K];
+        v4f Wt[2][K][2];
+        auto load_row = [&](int c, int r) {
+            const float *sp = sp0 + c * PLANE + r * PW;
+#pragma unroll
+            for (int j = 0; j < K; ++j) Ft[r][j] = sp[j];
+        };
+        auto load_w = [&](int buf, int c, int i) {
+            const float *wcur = wbuf + (c & 1) * (WLANES * 4) + i * K * Q;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                Wt[buf][j][0] = *reinterpret_cast<const v4f *>(wcur + j * Q);
+                Wt[buf][j][1] = *reinterpret_cast<const v4f *>(wcur + j * Q + 4);
+            }
+        };
+        v2f s[P][Q / 2];
+        auto zero_s = [&]() {
 #pragma unroll
             for (int pp = 0; pp < P; ++pp)
 #pragma unroll
                 for (int q = 0; q < Q / 2; ++q) s[pp][q] = v2f{0.0f, 0.0f};
-#if PBD_CONV_UNROLL_ROWS
-#pragma unroll
-#else
-#pragma clang loop unroll(disable)
-#endif
-            for (int i = 0; i < K; ++i) {
-                float fw[P][K];
-#pragma unroll
-                for (int pp = 0; pp < P; ++pp)
-#pragma unroll
-                    for (int j = 0; j < K; ++j) fw[pp][j] = sp[(pp + i) * PW + j];
-                v4f wa[K], wb[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    wa[j] = *reinterpret_cast<const v4f *>(wcur + (i * K + j) * Q);
-                    wb[j] = *reinterpret_cast<const v4f *>(wcur + (i * K + j) * Q + 4);
-                }
-                // every LDS read of this tap row is issued before the first multiply (counted lgkmcnt waits
-                // then retire them in order while the VALU works)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const v2f w[Q / 2] = {__builtin_shufflevector(wa[j], wa[j], 0, 1), __builtin_shufflevector(wa[j], wa[j], 2, 3),
-                                          __builtin_shufflevector(wb[j], wb[j], 0, 1), __builtin_shufflevector(wb[j], wb[j], 2, 3)};
-                    if (FMA) {
-#pragma unroll
-                        for (int pp = 0; pp < P; ++pp) {
-                            const v2f f = v2f{fw[pp][j], fw[pp][j]};
-#pragma unroll
-                            for (int q = 0; q < Q / 2; ++q) s[pp][q] = __builtin_elementwise_fma(w[q], f, s[pp][q]);
-                        }
-                    } else {
-                        // the 16 products of a tap first, then the 16 additions: a product is 16 instructions old
-                        // when its addition issues, so the two waves of a SIMD never wait on VALU latency
-                        // (back-to-back mul -> add pairs through one temporary left the VALU 71 % busy)
-                        v2f t[P][Q / 2];
-#pragma unroll
-                        for (int pp = 0; pp < P; ++pp) {
-                            const v2f f = v2f{fw[pp][j], fw[pp][j]};
-#pragma unroll
-                            for (int q = 0; q < Q / 2; ++q) t[pp][q] = w[q] * f;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int pp = 0; pp < P; ++pp)
-#pragma unroll
-                            for (int q = 0; q < Q / 2; ++q) s[pp][q] = s[pp][q] + t[pp][q];
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
+        };
+        auto add_s = [&]() {
 #pragma unroll
             for (int pp = 0; pp < P; ++pp)
 #pragma unroll
                 for (int q = 0; q < Q / 2; ++q) r[pp][q] = r[pp][q] + s[pp][q];
-            if (c + 1 < 32 && wl) *reinterpret_cast<v4f *>(wbuf + ((c + 1) & 1) * (WLANES * 4) + lane * 4) = wreg;
+        };
+        auto comp = [&](int wbi, int i) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const v4f wa = Wt[wbi][j][0], wb = Wt[wbi][j][1];
+                const v2f w[Q / 2] = {__builtin_shufflevector(wa, wa, 0, 1), __builtin_shufflevector(wa, wa, 2, 3),
+                                      __builtin_shufflevector(wb, wb, 0, 1), __builtin_shufflevector(wb, wb, 2, 3)};
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) {
+                    const v2f f = v2f{Ft[pp + i][j], Ft[pp + i][j]};
+#pragma unroll
+                    for (int q = 0; q < Q / 2; ++q) {
+                        if (FMA) s[pp][q] = __builtin_elementwise_fma(w[q], f, s[pp][q]);
+                        else s[pp][q] = s[pp][q] + w[q] * f;
+                    }
+                }
+            }
+        };
+        // stage = tap row i of a channel: rows 4..7 arrive during stages 0..3, the next channel's rows 0..3 during
+        // stage 4 (rows 0..3 are dead by then); nothing is conditional (the last iteration re-reads channel 31)
+        // The stages live in one basic block; to keep the compiler from sinking the packed operations below the
+        // loads of later stages, the 16 accumulators pass through an empty asm with a memory clobber at both ends
+        // of every stage (the loads cannot cross it, the operations are tied to it through their operands).
+#define PBD_PIN()                                                                                                          \
+    asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), \
+                 "+v"(s[1][3]), "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[2][2]), "+v"(s[2][3]), "+v"(s[3][0]), "+v"(s[3][1]),     \
+                 "+v"(s[3][2]), "+v"(s[3][3])::"memory")
+#define PBD_STAGE(LOADS, WB, I)                  \
+    do {                                         \
+        LOADS;                                   \
+        PBD_PIN();                               \
+        __builtin_amdgcn_sched_barrier(0);       \
+        comp(WB, I);                             \
+        PBD_PIN();                               \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#pragma unroll
+        for (int rr = 0; rr < P; ++rr) load_row(0, rr);
+        load_w(0, 0, 0);
+#pragma clang loop unroll(disable)
+        for (int c = 0; c < 32; c += 2) {
+            const int c2 = min(c + 2, 31);
+            // ---- channel c: weights slice 0; channel c+1's weights travel HBM -> wreg -> slice 1
+            if (wl) wreg = wsrc[(size_t)(c + 1) * (WCH / 4)];
+            zero_s();
+            PBD_STAGE(load_row(c, 4); load_w(1, c, 1), 0, 0);
+            PBD_STAGE(load_row(c, 5); load_w(0, c, 2), 1, 1);
+            PBD_STAGE(load_row(c, 6); load_w(1, c, 3), 0, 2);
+            if (wl) *reinterpret_cast<v4f *>(wbuf + WLANES * 4 + lane * 4) = wreg;
+            PBD_STAGE(load_row(c, 7); load_w(0, c, 4), 1, 3);
+            PBD_STAGE(load_row(c + 1, 0); load_row(c + 1, 1); load_row(c + 1, 2); load_row(c + 1, 3); load_w(1, c + 1, 0), 0, 4);
+            add_s();
+            // ---- channel c+1: slice 1; channel c+2 -> slice 0
+            if (wl) wreg = wsrc[(size_t)c2 * (WCH / 4)];
+            zero_s();
+            PBD_STAGE(load_row(c + 1, 4); load_w(0, c + 1, 1), 1, 0);
+            PBD_STAGE(load_row(c + 1, 5); load_w(1, c + 1, 2), 0, 1);
+            PBD_STAGE(load_row(c + 1, 6); load_w(0, c + 1, 3), 1, 2);
+            if (wl) *reinterpret_cast<v4f *>(wbuf + lane * 4) = wreg;
+            PBD_STAGE(load_row(c + 1, 7); load_w(1, c + 1, 4), 0, 3);
+            PBD_STAGE(load_row(c2, 0); load_row(c2, 1); load_row(c2, 2); load_row(c2, 3); load_w(0, c2, 0), 1, 4);
+            add_s();
         }
+#undef PBD_STAGE
+#undef PBD_PIN
         // a full group (all but possibly the last) stores without per-filter branches: one block of 8
         // independent stores per row
         if (g * Q + Q <= p.F) {
