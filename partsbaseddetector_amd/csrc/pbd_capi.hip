@@ -298,21 +298,21 @@ void finish_plan_tables(Plan &P)
     P.nrows_flat = (int)row2level.size();
     P.ncols_flat = (int)col2level.size();
     P.ntiles = (int)tiles.size();
-    // wave-private stack regions: a wave of 64 flat rows (columns) needs 64 x (longest row in the wave)
-    // entries; levels are ordered large to small, but take the maximum to be safe
+    // wave-private stack regions: a wave of 64 flat rows (columns) needs 64 x ceil(longest row in the wave / 2)
+    // two-entry records; levels are ordered large to small, but take the maximum to be safe
     std::vector<long long> srow, scol;
     long long tot_r = 0, tot_c = 0;
     for (int w0 = 0; w0 < P.nrows_flat; w0 += 64) {
         int mx = 0;
         for (int r = w0; r < std::min(w0 + 64, P.nrows_flat); ++r) mx = std::max(mx, P.lv[row2level[r]].cols);
         srow.push_back(tot_r);
-        tot_r += 64LL * mx;
+        tot_r += 64LL * ((mx + 1) / 2);
     }
     for (int w0 = 0; w0 < P.ncols_flat; w0 += 64) {
         int mx = 0;
         for (int c = w0; c < std::min(w0 + 64, P.ncols_flat); ++c) mx = std::max(mx, P.lv[col2level[c]].rows);
         scol.push_back(tot_c);
-        tot_c += 64LL * mx;
+        tot_c += 64LL * ((mx + 1) / 2);
     }
     P.stk_per_jf = std::max(tot_r, tot_c);
     (void)P.d_stk_row_off.upload(srow);
@@ -779,9 +779,9 @@ int dp_chunk_frames(pbd_handle *h, Plan &P, int want)
 {
     const size_t per_frame = (size_t)P.cell_per_frame * std::max(h->JGmax, 1);
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
-    const size_t budget = (size_t)8 << 30;   // bytes of scratch per chunk (14 B / cell-job + 12 B / stack entry)
+    const size_t budget = (size_t)8 << 30;   // bytes of scratch per chunk (12 B / cell-job + 16 B / two stack entries)
     int chunk = std::max(want, 1);
-    while (chunk > 1 && (per_frame * (8 + 2 * h->rs) + stk_per_frame * (h->f64 ? kStkEntryF64 : kStkEntryF32)) * chunk > budget) chunk = (chunk + 1) / 2;
+    while (chunk > 1 && (per_frame * (6 + 2 * h->rs) + stk_per_frame * (h->f64 ? kStkPairF64 : kStkPairF32)) * chunk > budget) chunk = (chunk + 1) / 2;
     return chunk;
 }
 
@@ -802,7 +802,7 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
-    HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkEntryF64 : kStkEntryF32), 16)));
+    HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkPairF64 : kStkPairF32), 16)));
     return PBD_OK;
 }
 

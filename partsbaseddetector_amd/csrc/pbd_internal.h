@@ -79,8 +79,8 @@ struct PartWalk {             // argmin tree walk, one per part of a component
 };
 
 constexpr int kMaxMix = 8;
-// bytes of one spilled envelope-stack entry {T z; T s; int v;} (natural alignment of T)
-constexpr size_t kStkEntryF32 = 12, kStkEntryF64 = 24;
+// bytes of one spilled PAIR of envelope-stack entries {T sa, sb, za; unsigned vv;} (natural alignment of T)
+constexpr size_t kStkPairF32 = 16, kStkPairF64 = 32;
 constexpr int kConvTW = 32, kConvTH = 8, kConvQ = 8;
 
 // ---- launch parameter blocks ---------------------------------------------------------------
@@ -142,8 +142,8 @@ struct DpParams {
     long long quad_per_frame;
     int16_t *IxT;                 // rows-pass pointers, transposed [x][y]
     int16_t *IxRaw, *IyRaw;       // row-major pointers written by the columns pass
-    void *stk;                    // [chunk][JG][stk_per_jf] 12-byte entries, wave-private, lane-interleaved
-    long long stk_per_jf;         // entries per (job, frame)
+    void *stk;                    // [chunk][JG][stk_per_jf] records of two entries, wave-private, lane-interleaved
+    long long stk_per_jf;         // records per (job, frame)
     const long long *stk_row_off; // per rows-pass wave (64 flat rows): first entry
     const long long *stk_col_off; // per columns-pass wave
     const DtJob *jobs;

@@ -38,16 +38,21 @@ template <> struct RealLimits<double> { static __device__ __forceinline__ double
 //   * the T entries below it live in a per-lane LDS ring (slot = index % T, arrays [T][64] so that a
 //     lane always hits bank lane % 32: conflict-free whatever the lanes' indices are); a pop is three
 //     ds_read_b32, a push three ds_write_b32;
-//   * only when a lane's ring overflows is its oldest entry spilled to the wave-private,
-//     lane-interleaved global stack ([k][lane], 12-byte entries), and only pops below the ring read it;
+//   * when a lane's ring is full its two oldest entries (2p, 2p+1) are spilled TOGETHER, as one 16-byte record
+//     {s[2p], s[2p+1], z[2p], v[2p] | v[2p+1] << 16}, to the wave-private, lane-interleaved global stack
+//     ([p][lane]); z[2p+1] is the intersection of the two, recomputed on reload with the same expression on the
+//     same operands (bit-identical).  With small deformation weights almost every parabola stays on the
+//     envelope, so nearly every entry makes this round trip, and since the lanes of a wave spill at different
+//     depths every lane's access is its own memory request: the passes are bound by the NUMBER of requests
+//     (a 6-byte s/v split over two stores was slower, doubling the fp64 divisions costs 3 %), which pairing halves;
 //   * the read-out walks q downwards and POPS: since z[1..ktop] is strictly increasing,
 //     "k = 0; while (z[k+1] < os) k++" (DistanceTransform.hpp:172-178, q ascending) selects the same
 //     k(q) = max{k : z[k] < os(q)} as "k = ktop; while (!(z[k] < os)) k--" with q descending;
 //   * source values are prefetched one chunk ahead and results leave in whole chunks.
 // The arithmetic per element is exactly computeRow's (DistanceTransform.hpp:152-182).
 // ------------------------------------------------------------------------------------------------
-template <typename R> struct StkEntryT { R z; R s; int v; };
-static_assert(sizeof(StkEntryT<float>) == kStkEntryF32 && sizeof(StkEntryT<double>) == kStkEntryF64, "host sizes the spill stack with these");
+template <typename R> struct StkPairT { R sa, sb, za; unsigned vv; };
+static_assert(sizeof(StkPairT<float>) == kStkPairF32 && sizeof(StkPairT<double>) == kStkPairF64, "host sizes the spill stack with these");
 
 #ifndef PBD_DT_CH
 #define PBD_DT_CH 8
@@ -69,17 +74,19 @@ struct DtRing {
     static constexpr int kSlotBytes = 64 * (2 * (int)sizeof(R) + 4);
     char *zs;                     // this lane's z of slot 0 (s is 64 R further)
     char *vp;                     // this lane's v of slot 0
-    StkEntryT<R> *g;              // this lane's column of the global [k][lane] stack
-    int lo;                       // ring holds indices [lo, top)
+    StkPairT<R> *g;               // this lane's column of the global [pair][lane] stack
+    double a, b;                  // the job's quadratic (z of the upper entry of a reloaded pair)
+    int lo;                       // ring holds indices [lo, top); lo is even; entries below lo are spilled
     __device__ __forceinline__ R &z(int slot) { return *reinterpret_cast<R *>(zs + slot * kSlotBytes); }
     __device__ __forceinline__ R &s(int slot) { return *reinterpret_cast<R *>(zs + slot * kSlotBytes + 64 * (int)sizeof(R)); }
     __device__ __forceinline__ int &v(int slot) { return *reinterpret_cast<int *>(vp + slot * kSlotBytes); }
     __device__ __forceinline__ void push_below(int idx, R zk, R sk, int vk)
     {   // entry `idx` (the old top) moves under a new top
         const int slot = idx & (kDtT - 1);
-        if (idx - lo >= kDtT) {   // slot still holds live entry idx - T: spill it
-            g[(size_t)(idx - kDtT) * 64] = StkEntryT<R>{z(slot), s(slot), v(slot)};
-            lo = idx - kDtT + 1;
+        if (idx - lo >= kDtT) {   // ring full: spill its two oldest entries lo, lo + 1 as one record
+            const int sl = lo & (kDtT - 1);
+            g[(size_t)(lo >> 1) * 64] = StkPairT<R>{s(sl), s(sl + 1), z(sl), (unsigned)v(sl) | ((unsigned)v(sl + 1) << 16)};
+            lo += 2;
         }
         z(slot) = zk; s(slot) = sk; v(slot) = vk;
     }
@@ -91,16 +98,22 @@ struct DtRing {
         zk = z(slot); sk = s(slot); vk = v(slot);
         asm volatile("" : "+v"(zk), "+v"(sk), "+v"(vk));   // keep these as LDS reads (not a flat load of a selected pointer)
         if (idx < lo) {
-            const StkEntryT<R> e = g[(size_t)idx * 64];
-            zk = e.z; sk = e.s; vk = e.v;
-            lo = idx;
+            // the ring is empty (idx == lo - 1, odd): reload the pair (lo-2, lo-1); the lower entry goes back
+            // into the ring, the upper one is the new top and gets its z recomputed
+            const StkPairT<R> e = g[(size_t)((lo - 2) >> 1) * 64];
+            const int va = (int)(e.vv & 0xffffu), vb = (int)(e.vv >> 16);
+            const int sl = (lo - 2) & (kDtT - 1);
+            z(sl) = e.za; s(sl) = e.sa; v(sl) = va;
+            sk = e.sb; vk = vb;
+            zk = quad_isect<R>(a, b, va, vb, e.sa, e.sb);   // as computed when entry lo-1 was pushed onto entry lo-2
+            lo -= 2;
         }
     }
     // the ring of wave `w` of the workgroup inside `smem`
-    static __device__ __forceinline__ DtRing make(char *smem, int w, int lane, StkEntryT<R> *g)
+    static __device__ __forceinline__ DtRing make(char *smem, int w, int lane, StkPairT<R> *g, double a, double b)
     {
         char *base = smem + (size_t)w * kDtT * kSlotBytes;
-        return DtRing{base + lane * (int)sizeof(R), base + 128 * (int)sizeof(R) + lane * 4, g, 0};
+        return DtRing{base + lane * (int)sizeof(R), base + 128 * (int)sizeof(R) + lane * 4, g, a, b, 0};
     }
 };
 
@@ -203,8 +216,8 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     int16_t *ixT = p.IxT + obase;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
-                                     reinterpret_cast<StkEntryT<R> *>(p.stk) +
-                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane);
+                                     reinterpret_cast<StkPairT<R> *>(p.stk) +
+                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane, job.ax, job.bx);
     const int N = active ? W : 0;
     if (N == 0) return;
     auto load = [&](int q0, R *buf) {
@@ -260,8 +273,8 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
     int16_t *ixr = p.IxRaw + jbase + x;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
-                                     reinterpret_cast<StkEntryT<R> *>(p.stk) +
-                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane);
+                                     reinterpret_cast<StkPairT<R> *>(p.stk) +
+                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane, job.ay, job.by);
     auto load = [&](int q0, R *buf) {
         if (sizeof(R) == 4 && q0 + kDtCH <= H) {
             const float *srcf = reinterpret_cast<const float *>(tmpT);
