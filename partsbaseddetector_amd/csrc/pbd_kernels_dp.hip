@@ -55,7 +55,7 @@ template <typename R> struct StkPairT { R sa, sb, za; unsigned vv; };
 static_assert(sizeof(StkPairT<float>) == kStkPairF32 && sizeof(StkPairT<double>) == kStkPairF64, "host sizes the spill stack with these");
 
 #ifndef PBD_DT_CH
-#define PBD_DT_CH 8
+#define PBD_DT_CH 16
 #endif
 constexpr int kDtCH = PBD_DT_CH;   // elements per streamed chunk (multiple of 4)
 #ifndef PBD_DT_WAVES
