@@ -704,7 +704,7 @@ int build_model(pbd_handle *h, const pbd_model *m)
 // [f0, f0+nb) on stream `st` (no allocation, no synchronisation inside).
 int alloc_features(pbd_handle *h, Plan &P, int nframes)
 {
-    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * P.cn));
+    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * P.cn + 4));   // +4: pixels are read as one 32-bit load
     HIPCHK(h, h->gmag.ensure((size_t)nframes * P.pix_per_frame * h->rs));
     HIPCHK(h, h->gori.ensure((size_t)nframes * P.pix_per_frame));
     HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * h->rs));

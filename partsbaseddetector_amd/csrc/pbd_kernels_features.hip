@@ -23,6 +23,14 @@ __device__ __forceinline__ int find_level(const LevelDesc *lv, int lo, int hi, l
     return lo;
 }
 
+// The three bytes of a BGR pixel in one (unaligned) 32-bit load: byte loads cost a full memory instruction
+// each, and these kernels are bound by the number of them.  The fourth byte belongs to the next pixel (the
+// pyramid buffer carries 4 bytes of slack; callers' frames use the byte path for their very last pixel).
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t load_px3(const uint8_t *q) { return *reinterpret_cast<const u32_unaligned *>(q); }
+__device__ __forceinline__ uint32_t load_px3_bytes(const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16); }
+__device__ __forceinline__ int px_ch(uint32_t v, int c) { return (int)((v >> (8 * c)) & 0xffu); }
+
 // ------------------------------------------------------------------------------------------------
 // cv::resize, INTER_LINEAR, 8-bit (call site src/HOGFeatures.cpp:116).  Coefficient tables are
 // built on the host (pbd_plan.cpp); here: horizontal pass in int, vertical pass
@@ -44,6 +52,20 @@ __global__ __launch_bounds__(256) void k_resize(PyrParams p, long long npix)
     const uint8_t *S0 = src + (size_t)ty.y0 * p.cols * cn, *S1 = src + (size_t)ty.y1 * p.cols * cn;
     const int sx = tx.sx, sx1 = sx + 1 < p.cols ? sx + 1 : sx;
     uint8_t *D = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off + local) * cn;
+    if (cn == 3) {
+        // the last pixel of the caller's frame is read bytewise (no 4th byte to touch)
+        auto ld = [&](const uint8_t *row, int yy, int xx) {
+            return (yy == p.rows - 1 && xx == p.cols - 1) ? load_px3_bytes(row + xx * 3) : load_px3(row + xx * 3);
+        };
+        const uint32_t p00 = ld(S0, ty.y0, sx), p10 = ld(S1, ty.y1, sx), p01 = ld(S0, ty.y0, sx1), p11 = ld(S1, ty.y1, sx1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int r0 = px_ch(p00, c) * tx.a0 + px_ch(p01, c) * tx.a1;
+            const int r1 = px_ch(p10, c) * tx.a0 + px_ch(p11, c) * tx.a1;
+            D[c] = (uint8_t)((((ty.b0 * (r0 >> 4)) >> 16) + ((ty.b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+        }
+        return;
+    }
     for (int c = 0; c < cn; ++c) {
         const int r0 = S0[sx * cn + c] * tx.a0 + S0[sx1 * cn + c] * tx.a1;
         const int r1 = S1[sx * cn + c] * tx.a0 + S1[sx1 * cn + c] * tx.a1;
@@ -87,6 +109,22 @@ __global__ __launch_bounds__(256) void k_pyrdown(PyrParams p, int first_level, i
     for (int k = 0; k < 5; ++k) {
         xs[k] = reflect101(2 * x - 2 + k, sd.img_cols) * cn;
         ys[k] = reflect101(2 * y - 2 + k, sd.img_rows);
+    }
+    if (cn == 3) {
+        int r[5][3];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint8_t *R = S + (size_t)ys[k] * sd.img_cols * 3;
+            uint32_t q[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] = load_px3(R + xs[i]);      // source levels live in the pyramid buffer (slack at its end)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                r[k][c] = px_ch(q[2], c) * 6 + (px_ch(q[1], c) + px_ch(q[3], c)) * 4 + px_ch(q[0], c) + px_ch(q[4], c);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) D[c] = (uint8_t)((r[2][c] * 6 + (r[1][c] + r[3][c]) * 4 + r[0][c] + r[4][c] + 128) >> 8);
+        return;
     }
     for (int c = 0; c < cn; ++c) {
         int r[5];
@@ -146,14 +184,15 @@ __global__ __launch_bounds__(256) void k_hog_grad(HogParams p)
         v = dx * dx + dy * dy;
     } else {
         const uint8_t *s = im + 3 * xs + (size_t)ys * stride;
-        const R dyb = (R)((int)s[stride] - (int)*(s - stride));
-        const R dxb = (R)((int)s[3] - (int)s[-3]);
+        const uint32_t pd = load_px3(s + stride), pu = load_px3(s - stride), pr = load_px3(s + 3), pl = load_px3(s - 3);
+        const R dyb = (R)(px_ch(pd, 0) - px_ch(pu, 0));
+        const R dxb = (R)(px_ch(pr, 0) - px_ch(pl, 0));
         const R vb = dxb * dxb + dyb * dyb;
-        const R dyg = (R)((int)s[stride + 1] - (int)*(s - stride + 1));
-        const R dxg = (R)((int)s[4] - (int)s[-2]);
+        const R dyg = (R)(px_ch(pd, 1) - px_ch(pu, 1));
+        const R dxg = (R)(px_ch(pr, 1) - px_ch(pl, 1));
         const R vg = dxg * dxg + dyg * dyg;
-        dy = (R)((int)s[stride + 2] - (int)*(s - stride + 2));
-        dx = (R)((int)s[5] - (int)s[-1]);
+        dy = (R)(px_ch(pd, 2) - px_ch(pu, 2));
+        dx = (R)(px_ch(pr, 2) - px_ch(pl, 2));
         v = dx * dx + dy * dy;
         if (vg > v) { v = vg; dx = dxg; dy = dyg; }
         if (vb > v) { v = vb; dx = dxb; dy = dyb; }
