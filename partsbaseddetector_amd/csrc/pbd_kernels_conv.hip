@@ -158,10 +158,16 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) {
                     const v2f f = v2f{Ft[pp + i][j], Ft[pp + i][j]};
+                    if (FMA) {
 #pragma unroll
-                    for (int q = 0; q < Q / 2; ++q) {
-                        if (FMA) s[pp][q] = __builtin_elementwise_fma(w[q], f, s[pp][q]);
-                        else s[pp][q] = s[pp][q] + w[q] * f;
+                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = __builtin_elementwise_fma(w[q], f, s[pp][q]);
+                    } else {
+                        // four products, then their four additions: an addition issues 16 cycles after its product
+                        v2f tq[Q / 2];
+#pragma unroll
+                        for (int q = 0; q < Q / 2; ++q) tq[q] = w[q] * f;
+#pragma unroll
+                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = s[pp][q] + tq[q];
                     }
                 }
             }
