@@ -409,3 +409,29 @@ def test_mfma_f16_mode(det_mod, oracle):
     assert len(res["exact"]) > 0
     assert len(common) >= 0.9 * max(len(res["exact"]), len(res["f16"]))
     assert dscore <= 5e-2
+
+
+@pytest.mark.parametrize("ksize", [3, 7])
+def test_training_demo_configuration(det_mod, oracle, ksize):
+    """The reference's in-tree example model geometry (matlab/training_demo.m:5,12,29: K = [4 4 4 4 4 4],
+    pa = [0 1 1 3 2 4], sbin = 8) with 3x3 / 7x7 filters: sbin 8 HOG, the generic-size convolution kernel and a
+    6-part tree, every stage bit for bit against the oracle."""
+    model = M.synthetic_model(seed=11, pa=[0, 1, 1, 3, 2, 4], nmix=4, ksize=ksize, sbin=8, interval=5, thresh=-1e9,
+                              name="training-demo")
+    flat = model.flatten()
+    im = synth.synthetic_frame(33, 200, 264, 3)
+    want = oracle.detect(flat, im)
+    model.thresh = float(np.sort([w["score"] for w in want])[-40])      # keep the 40 best roots
+    flat = model.flatten()
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    got = det.detect(im)
+    want = oracle.detect(flat, im)
+    assert len(want) >= 30
+    _compare_candidates(got, want)
+    feats, _ = oracle.features_pyramid(flat, im)
+    for l in (0, len(feats) - 1):
+        H, W = feats[l].shape[0], feats[l].shape[1] // 32
+        assert np.array_equal(det.hd.get_stage(0, 0, l, H, W).view(np.uint32), feats[l].view(np.uint32))
+        assert np.array_equal(det.hd.get_stage(1, 0, l, H, W).view(np.uint32), oracle.responses(flat, feats[l]).view(np.uint32))
+    det.hd.close()
