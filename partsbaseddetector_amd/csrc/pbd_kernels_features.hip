@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void k_hog_grad(HogParams p)
 // of the pixel's orientation.  The 18 bins of a thread live in LDS ([18][256], the thread always hits bank
 // tid % 32), so the update is one read-add-write instead of 18 predicated register adds; the sequence of
 // float additions per bin is the reference's.  Also writes the block energy (:270-283).
-template <typename R>
+// SB = compile-time sbin (4, 8) or 0 for any: with a known sbin the x weights of the thread's window are fetched
+// once into registers instead of once per source pixel (the coordinate-table loads were most of the kernel's
+// memory requests: lanes are blocks, their table entries sbin apart).
+template <typename R, int SB>
 __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
 {
     __shared__ R bins[18 * 256];
@@ -245,6 +248,38 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
     if (xhi > visw - 1) xhi = visw - 1;
     if (!active) yhi = ylo;
 
+    if constexpr (SB > 0) {
+        constexpr int NX = 2 * SB + 2;                         // window width before clamping
+        const int x0 = SB * bx - (SB + 1) / 2 - 1;
+        R wxs[NX];
+        int xoff[NX];                                           // source column, -1: this x does not feed the block
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int x = x0 + i;
+            xoff[i] = -1; wxs[i] = (R)0;
+            if (x >= xlo && x < xhi) {
+                const HogCoordT<R> cx = coord[x];
+                if (cx.ip == bx) { wxs[i] = cx.v1; xoff[i] = x < cols - 2 ? x : cols - 2; }
+                else if (cx.ip + 1 == bx) { wxs[i] = cx.v0; xoff[i] = x < cols - 2 ? x : cols - 2; }
+            }
+        }
+        for (int y = ylo; y < yhi; ++y) {
+            const HogCoordT<R> cy = coord[y];
+            R wy;
+            if (cy.ip == by) wy = cy.v1;
+            else if (cy.ip + 1 == by) wy = cy.v0;
+            else continue;
+            const size_t rowg = (size_t)(y < rows - 2 ? y : rows - 2) * cols;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                if (xoff[i] < 0) continue;
+                const size_t g = rowg + xoff[i];
+                const R contrib = (wy * wxs[i]) * gmag[g];
+                R *bin = h + (int)gori[g] * 256;
+                *bin = *bin + contrib;
+            }
+        }
+    } else
     for (int y = ylo; y < yhi; ++y) {
         const HogCoordT<R> cy = coord[y];
         R wy;
@@ -286,8 +321,10 @@ void launch_hog_hist(const HogParams &p, int nframes, bool f64, hipStream_t s)
     if (f64) hipLaunchKernelGGL(k_hog_grad<double>, gridp, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_hog_grad<float>, gridp, dim3(256), 0, s, p);
     dim3 grid((unsigned)((p.blk_per_frame + 255) / 256), nframes);
-    if (f64) hipLaunchKernelGGL(k_hog_hist<double>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_hog_hist<float>, grid, dim3(256), 0, s, p);
+    if (f64) hipLaunchKernelGGL((k_hog_hist<double, 0>), grid, dim3(256), 0, s, p);
+    else if (p.sbin == 4) hipLaunchKernelGGL((k_hog_hist<float, 4>), grid, dim3(256), 0, s, p);
+    else if (p.sbin == 8) hipLaunchKernelGGL((k_hog_hist<float, 8>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_hog_hist<float, 0>), grid, dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
