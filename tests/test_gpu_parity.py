@@ -435,3 +435,36 @@ def test_training_demo_configuration(det_mod, oracle, ksize):
         assert np.array_equal(det.hd.get_stage(0, 0, l, H, W).view(np.uint32), feats[l].view(np.uint32))
         assert np.array_equal(det.hd.get_stage(1, 0, l, H, W).view(np.uint32), oracle.responses(flat, feats[l]).view(np.uint32))
     det.hd.close()
+
+
+def test_config2_gpu_features_conv_host_dp(det_mod, oracle):
+    """BASELINE configs[1]: person model, one 640x480 frame, HOG + convolution on the GPU through the staged
+    IFeatures / IConvolutionEngine surface, responses back on the host, DynamicProgram::min/argmin on the host
+    (CPU restatement).  The candidates must equal the all-CPU and the all-GPU results."""
+    model = M.synthetic_person_model()
+    flat = model.flatten()
+    im = synth.synthetic_frame(2, 480, 640, 3)
+    hd = _handle(det_mod, flat)
+    fe = det_mod.HOGFeatures(hd)
+    feats = fe.pyramid(im)
+    resp = det_mod.SpatialConvolutionEngine(hd).pdf(feats)       # responses[level] = (nfilters, H, W) on the host
+    scales = fe.scales()
+    hd.close()
+    assert len(resp) == 46 and sum(r.shape[1] * r.shape[2] for r in resp) == 140725      # SURVEY.md Appendix B
+    host = []
+    for l, r in enumerate(resp):
+        if r.shape[1] == 0 or r.shape[2] == 0:
+            continue
+        for c in range(flat.ncomponents):
+            Ix, Iy, Ik, rootv, rooti = oracle.dp_min(flat, c, r)
+            host += oracle.dp_argmin(flat, c, l, float(scales[l]), Ix, Iy, Ik, rootv, rooti)
+    host.sort(key=lambda w: (w["level"], w["component"], w["root_y"], w["root_x"]))
+    want = oracle.detect(flat, im)
+    assert len(want) > 0 and len(host) == len(want)
+    for a, b in zip(host, want):
+        assert _cand_key(a) == _cand_key(b) and np.array_equal(a["parts"], b["parts"])
+        assert np.float32(a["score"]) == np.float32(b["score"])
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    _compare_candidates(det.detect(im), want)
+    det.hd.close()
