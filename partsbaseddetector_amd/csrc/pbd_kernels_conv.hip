@@ -158,16 +158,19 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) {
                     const v2f f = v2f{Ft[pp + i][j], Ft[pp + i][j]};
+                    // the first tap of a channel starts the sum: s = 0 + w*f (src/filter.cpp:3916), no separate zeroing
+                    const bool first = (i == 0 && j == 0);
+                    const v2f zero2 = v2f{0.0f, 0.0f};
                     if (FMA) {
 #pragma unroll
-                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = __builtin_elementwise_fma(w[q], f, s[pp][q]);
+                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = __builtin_elementwise_fma(w[q], f, first ? zero2 : s[pp][q]);
                     } else {
                         // four products, then their four additions: an addition issues 16 cycles after its product
                         v2f tq[Q / 2];
 #pragma unroll
                         for (int q = 0; q < Q / 2; ++q) tq[q] = w[q] * f;
 #pragma unroll
-                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = s[pp][q] + tq[q];
+                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = (first ? zero2 : s[pp][q]) + tq[q];
                     }
                 }
             }
@@ -193,12 +196,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #pragma unroll
         for (int rr = 0; rr < P; ++rr) load_row(0, rr);
         load_w(0, 0, 0);
+        zero_s();                      // defined values for the first pin; every channel starts its own sum
 #pragma clang loop unroll(disable)
         for (int c = 0; c < 32; c += 2) {
             const int c2 = min(c + 2, 31);
             // ---- channel c: weights slice 0; channel c+1's weights travel HBM -> wreg -> slice 1
             if (wl) wreg = wsrc[(size_t)(c + 1) * (WCH / 4)];
-            zero_s();
             PBD_STAGE(load_row(c, 4); load_w(1, c, 1), 0, 0);
             PBD_STAGE(load_row(c, 5); load_w(0, c, 2), 1, 1);
             PBD_STAGE(load_row(c, 6); load_w(1, c, 3), 0, 2);
@@ -208,7 +211,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
             add_s();
             // ---- channel c+1: slice 1; channel c+2 -> slice 0
             if (wl) wreg = wsrc[(size_t)c2 * (WCH / 4)];
-            zero_s();
             PBD_STAGE(load_row(c + 1, 4); load_w(0, c + 1, 1), 1, 0);
             PBD_STAGE(load_row(c + 1, 5); load_w(1, c + 1, 2), 0, 1);
             PBD_STAGE(load_row(c + 1, 6); load_w(0, c + 1, 3), 1, 2);
