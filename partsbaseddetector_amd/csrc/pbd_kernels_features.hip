@@ -31,6 +31,21 @@ __device__ __forceinline__ uint32_t load_px3(const uint8_t *q) { return *reinter
 __device__ __forceinline__ uint32_t load_px3_bytes(const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16); }
 __device__ __forceinline__ int px_ch(uint32_t v, int c) { return (int)((v >> (8 * c)) & 0xffu); }
 
+// Block-cooperative variant: the offsets of the candidate levels go to LDS in ONE memory round trip and the
+// search runs there.  (The per-thread search above is six DEPENDENT global loads -- ~4000 cycles before a wave's
+// first useful instruction -- and was what bounded these short kernels.)  Every thread of the block must call it.
+template <int OFF>
+__device__ __forceinline__ int find_level_blk(const LevelDesc *lv, int lo, int hi, long long idx, long long *s_off)
+{
+    for (int i = lo + (int)threadIdx.x; i < hi; i += (int)blockDim.x) s_off[i] = lv_off<OFF>(lv[i]);
+    __syncthreads();
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= idx) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // ------------------------------------------------------------------------------------------------
 // cv::resize, INTER_LINEAR, 8-bit (call site src/HOGFeatures.cpp:116).  Coefficient tables are
 // built on the host (pbd_plan.cpp); here: horizontal pass in int, vertical pass
@@ -38,10 +53,11 @@ __device__ __forceinline__ int px_ch(uint32_t v, int c) { return (int)((v >> (8 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resize(PyrParams p, long long npix)
 {
+    __shared__ long long s_off[PBD_MAX_LEVELS];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = find_level_blk<0>(p.lv, 0, p.interval, idx, s_off);
     if (idx >= npix) return;
     const int frame = p.frame0 + blockIdx.y;
-    const int l = find_level<0>(p.lv, 0, p.interval, idx);
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.img_off);
     const int dy = local / d.img_cols, dx = local - dy * d.img_cols;
@@ -93,10 +109,11 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 __global__ __launch_bounds__(256) void k_pyrdown(PyrParams p, int first_level, int last_level, long long base, long long npix)
 {
+    __shared__ long long s_off[PBD_MAX_LEVELS];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = find_level_blk<0>(p.lv, first_level, last_level, idx + base, s_off);
     if (idx >= npix) return;
     const int frame = p.frame0 + blockIdx.y;
-    const int l = find_level<0>(p.lv, first_level, last_level, idx + base);
     const LevelDesc d = p.lv[l];
     const LevelDesc sd = p.lv[d.src_level];
     const int local = (int)(idx + base - d.img_off);
@@ -161,10 +178,11 @@ template <> __device__ __forceinline__ double real_sqrt<double>(double v) { retu
 template <typename R>
 __global__ __launch_bounds__(256) void k_hog_grad(HogParams p)
 {
+    __shared__ long long s_off[PBD_MAX_LEVELS];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = find_level_blk<0>(p.lv, 0, p.nlevels, idx, s_off);
     if (idx >= p.pix_per_frame) return;
     const int frame = p.frame0 + blockIdx.y;
-    const int l = find_level<0>(p.lv, 0, p.nlevels, idx);
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.img_off);
     const int rows = d.img_rows, cols = d.img_cols;
@@ -224,7 +242,8 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
     const bool active = idx0 < p.blk_per_frame;
     const long long idx = active ? idx0 : p.blk_per_frame - 1;
     const int frame = p.frame0 + blockIdx.y;
-    const int l = find_level<1>(p.lv, 0, p.nlevels, idx);
+    __shared__ long long s_off[PBD_MAX_LEVELS];
+    const int l = find_level_blk<1>(p.lv, 0, p.nlevels, idx, s_off);
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.blk_off);
     const int by = local / d.blk_cols, bx = local - by * d.blk_cols;
@@ -341,10 +360,11 @@ __device__ __forceinline__ R hog_norm(const R *n, int stride)
 template <typename R>
 __global__ __launch_bounds__(256) void k_hog_feat(HogParams p)
 {
+    __shared__ long long s_off[PBD_MAX_LEVELS];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = find_level_blk<2>(p.lv, 0, p.nlevels, idx, s_off);
     if (idx >= p.cell_per_frame) return;
     const int frame = p.frame0 + blockIdx.y;
-    const int l = find_level<2>(p.lv, 0, p.nlevels, idx);
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.cell_off);
     const int y = local / d.cols, x = local - y * d.cols;
