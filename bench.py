@@ -110,12 +110,13 @@ def main():
     cap_g = 8192
     dev = torch.device("cuda", local_rank)
 
+    gatherer = pdist.CandidateGatherer(stride, cap_g, dev if args.backend == "nccl" else "cpu") if world > 1 else None
+
     def step():
         buf, n = det.detect_batch_device(d_frames.data_ptr(), B, rows, cols, cn, raw=True)
         if world > 1:
-            rec = pdist.gather_candidates(buf, n, stride, cap_g, frame_offset=rank * B,
-                                          device=dev if args.backend == "nccl" else "cpu")
-            return len(rec)
+            rec = gatherer.gather(buf, n, frame_offset=rank * B, root_only=True)      # rank 0 holds the whole list
+            return len(rec) if rec is not None else n
         return n
 
     def sync():

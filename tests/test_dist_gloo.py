@@ -84,3 +84,51 @@ def test_gather_candidates_world2(world, nframes):
         for j in range(1 + f % 3):
             want.append([f] + [1000 * f + j] * (stride - 1))
     assert np.array_equal(got, np.asarray(want, np.int32).reshape(-1, stride))
+
+
+def _gatherer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from partsbaseddetector_amd import dist as pd
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        stride = 12
+        g = pd.CandidateGatherer(stride, cap=32, device="cpu")
+        out = []
+        for step in range(3):                          # buffers are reused across steps
+            n = 3 + rank + step
+            buf = (np.arange(n * stride, dtype=np.int32) + 1000 * rank + 7 * step).copy()
+            buf.reshape(n, stride)[:, 0] = np.arange(n)
+            rec = g.gather(buf, n, frame_offset=100 * rank, root_only=(step == 2))
+            out.append(None if rec is None else rec.copy())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_candidate_gatherer_world2():
+    """CandidateGatherer (what bench.py uses for N > 1): same records as the one-shot gather, every step,
+    root_only leaves the other rank without a copy."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29655
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    stride = 12
+    for step in range(3):
+        want = []
+        for rank in range(2):
+            n = 3 + rank + step
+            b = (np.arange(n * stride, dtype=np.int32) + 1000 * rank + 7 * step).reshape(n, stride).copy()
+            b[:, 0] = np.arange(n) + 100 * rank
+            want.append(b)
+        want = np.concatenate(want)
+        assert np.array_equal(res[0][step], want)
+        if step == 2:
+            assert res[1][step] is None
+        else:
+            assert np.array_equal(res[1][step], want)
