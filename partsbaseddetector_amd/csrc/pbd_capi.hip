@@ -997,6 +997,19 @@ const char *pbd_version(void) { return "pbd-hip 0.1 (gfx950)"; }
 
 // diagnostics, not part of include/pbd.h
 int pbd_debug_conv_occupancy(int nw) { return conv_occupancy(nw); }
+// the convolution's tile cover of one rows x cols level (host-only, no GPU needed): out[i] = {shape, y0, x0}
+int pbd_debug_cover_level(int rows, int cols, int *out, int capacity)
+{
+    std::vector<ConvTile> shaped[3];
+    cover_level(0, rows, cols, shaped);
+    int n = 0;
+    for (int k = 0; k < 3; ++k)
+        for (const ConvTile &t : shaped[k]) {
+            if (n < capacity) { out[3 * n] = k; out[3 * n + 1] = t.y0; out[3 * n + 2] = t.x0; }
+            ++n;
+        }
+    return n;
+}
 
 const char *pbd_last_error(const pbd_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 

@@ -71,3 +71,38 @@ def test_python_mirror_has_reference_method_names():
                          d.Candidate: ["score", "sort"]}.items():
         for m in methods:
             assert hasattr(cls, m), (cls, m)
+
+
+def test_conv_tile_cover_is_complete_and_minimal():
+    """Host logic of the convolution's mixed-shape tiling (pbd_capi.hip: cover_level), no GPU needed: every cell
+    of a level is covered by a tile, and the number of lanes spent equals the optimum of the same dynamic
+    program written independently here (strips of 32x8 / 16x16 / 8x32 tiles chosen over the columns)."""
+    import ctypes as C
+    import math
+    import numpy as np
+    from partsbaseddetector_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH) if hasattr(_lib, "LIB_PATH") else _lib.load()
+    fn = lib.pbd_debug_cover_level
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    shapes = [(32, 8), (16, 16), (8, 32)]
+    rng = np.random.default_rng(4)
+    cases = [(118, 158), (1, 1), (5, 7), (8, 32), (33, 17), (268, 478)] + [tuple(int(v) for v in rng.integers(1, 200, 2)) for _ in range(40)]
+    for rows, cols in cases:
+        buf = (C.c_int * (3 * 4096))()
+        n = fn(rows, cols, buf, 4096)
+        assert 0 < n <= 4096
+        cover = np.zeros((rows, cols), np.int32)
+        lanes = 0
+        for i in range(n):
+            k, y0, x0 = buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]
+            tw, th = shapes[k]
+            assert 0 <= y0 < rows and 0 <= x0 < cols and y0 % th == 0
+            cover[y0:y0 + th, x0:x0 + tw] += 1
+            lanes += tw * th
+        assert cover.min() >= 1, (rows, cols)
+        best = [0] + [10 ** 12] * cols
+        for w in range(1, cols + 1):
+            for tw, th in shapes:
+                best[w] = min(best[w], best[max(w - tw, 0)] + tw * math.ceil(rows / th) * th)
+        assert lanes == best[cols], (rows, cols, lanes, best[cols])
