@@ -216,11 +216,22 @@ def main():
             nf = max(1, args.cpu_frames)
             oracle.detect(flat, frames[0])            # warm-up (page-in, thread pool)
             t1 = time.perf_counter()
+            stage = {}
             for i in range(nf):
-                oracle.detect(flat, frames[i % B])
+                _, ms = oracle.detect(flat, frames[i % B], want_stage_ms=True)
+                for k, v in ms.items():
+                    stage[k] = stage.get(k, 0.0) + v / nf
             cdt = time.perf_counter() - t1
+            # one frame on a single thread as well ("time 1 thread and all cores")
+            oracle.set_num_threads(1)
+            t1 = time.perf_counter()
+            oracle.detect(flat, frames[0])
+            c1 = time.perf_counter() - t1
+            oracle.set_num_threads(ncpu)
             cpu = {"value": round(nf / cdt, 4), "unit": "detections/s", "cores": oracle.num_threads(), "kind": "port",
-                   "sample": f"{nf} of the same {cols}x{rows} frames, full path, OpenMP at the reference's 5 sites"}
+                   "sample": f"{nf} of the same {cols}x{rows} frames, full path, OpenMP at the reference's 5 sites",
+                   "stage_ms_per_frame": {k: round(v, 2) for k, v in stage.items()},
+                   "single_thread": {"value": round(1.0 / c1, 4), "unit": "detections/s", "cores": 1, "sample": "1 frame"}}
         other_mode, agreement = None, None
         if world == 1 and args.conv_mode in ("exact", "mfma") and not args.no_other:
             # the other convolution mode on the same resident batch: exact <-> matrix cores
