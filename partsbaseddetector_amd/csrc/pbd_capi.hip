@@ -183,6 +183,7 @@ struct pbd_handle {
     std::vector<PartWalk> walk;
     std::vector<int> walk_off;
     int JGmax = 0;
+    int max_mix = 1;                 // largest number of mixtures of any part
     bool filters_set = false;
 
     // device model tables
@@ -580,6 +581,7 @@ int build_model(pbd_handle *h, const pbd_model *m)
             const int gp = p0 + p, par = h->parentid[gp];
             const int K = h->mix_offset[gp + 1] - h->mix_offset[gp];
             if (K < 1 || K > kMaxMix) return fail(h, PBD_ERR_UNSUPPORTED, "part %d has %d mixtures (1..%d supported)", p, K, kMaxMix);
+            h->max_mix = std::max(h->max_mix, K);
             if ((p == 0) != (par < 0) || par >= p) return fail(h, PBD_ERR_INVALID, "part %d: parent %d breaks topological order", p, par);
             for (int mm = 0; mm < K; ++mm) {
                 const int f = h->filterid[h->mix_offset[gp] + mm];
@@ -811,7 +813,7 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
 {
     DpParams dp{};
     dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC; dp.NM = h->NM;
-    dp.cell_per_frame = P.cell_per_frame; dp.quad_per_frame = P.quad_per_frame;
+    dp.cell_per_frame = P.cell_per_frame; dp.quad_per_frame = P.quad_per_frame; dp.max_mix = h->max_mix;
     dp.resp = h->resp.p; dp.acc = h->acc.p;
     dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;

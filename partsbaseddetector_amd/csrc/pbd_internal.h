@@ -140,6 +140,7 @@ struct DpParams {
     int JG;                       // jobs in this group
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
     long long quad_per_frame;
+    int max_mix;                  // largest number of mixtures of any part of the model (<= kMaxMix)
     int16_t *IxT;                 // rows-pass pointers, transposed [x][y]
     int16_t *IxRaw, *IyRaw;       // row-major pointers written by the columns pass
     void *stk;                    // [chunk][JG][stk_per_jf] records of two entries, wave-private, lane-interleaved

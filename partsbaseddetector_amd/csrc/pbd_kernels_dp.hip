@@ -361,7 +361,8 @@ __device__ __forceinline__ void store_cells(T *dst, int n, const T *src)
     }
 }
 
-template <typename R, int kCpt>
+// MAXM: compile-time bound on the mixtures per part of the model (register arrays are sized by it)
+template <typename R, int kCpt, int MAXM>
 __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
 {
     constexpr int SUB = 4 / kCpt;   // threads per group of 4 cells
@@ -386,9 +387,9 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
     const R *dtp = static_cast<const R *>(p.dt);
     const size_t gbase0 = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG;
     const size_t pbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + local;
-    R accv[kMaxMix][kCpt];
+    R accv[MAXM][kCpt];
 #pragma unroll
-    for (int pm = 0; pm < kMaxMix; ++pm) {
+    for (int pm = 0; pm < MAXM; ++pm) {
 #pragma unroll
         for (int e = 0; e < kCpt; ++e) accv[pm][e] = (R)0;
         if (pm < cj.npar) load_cells<R, kCpt>(resp + (size_t)cj.filter[pm] * HW, n, accv[pm]);
@@ -408,16 +409,16 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
             for (int k = 0; k < 8; ++k) cd.bias_off[k] = ci[3 + k];
         }
         const size_t gbase = gbase0 + (size_t)cd.job_begin * HW;
-        float bw[kMaxMix][kMaxMix]; // bias(mm)[pm]
+        float bw[MAXM][MAXM]; // bias(mm)[pm]
 #pragma unroll
-        for (int mm = 0; mm < kMaxMix; ++mm)
+        for (int mm = 0; mm < MAXM; ++mm)
 #pragma unroll
-            for (int pm = 0; pm < kMaxMix; ++pm)
+            for (int pm = 0; pm < MAXM; ++pm)
                 bw[mm][pm] = (mm < cd.nmix && pm < cj.npar) ? biasw[cd.bias_off[mm] + pm] : 0.0f;
-        R dtv[kMaxMix][kCpt];
-        int16_t ixv[kMaxMix][kCpt];
+        R dtv[MAXM][kCpt];
+        int16_t ixv[MAXM][kCpt];
 #pragma unroll
-        for (int mm = 0; mm < kMaxMix; ++mm) {
+        for (int mm = 0; mm < MAXM; ++mm) {
 #pragma unroll
             for (int e = 0; e < kCpt; ++e) { dtv[mm][e] = (R)0; ixv[mm][e] = 0; }
             if (mm < cd.nmix) {
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
             }
         }
 #pragma unroll
-        for (int pm = 0; pm < kMaxMix; ++pm) {
+        for (int pm = 0; pm < MAXM; ++pm) {
             if (pm < cj.npar) {
                 int16_t oix[kCpt], oiy[kCpt];
                 uint8_t oik[kCpt];
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
                     } else {
                         best = -RealLimits<R>::inf();
 #pragma unroll
-                        for (int mm = 0; mm < kMaxMix; ++mm) {
+                        for (int mm = 0; mm < MAXM; ++mm) {
                             if (mm < cd.nmix) {
                                 const R wv = dtv[mm][e] + (R)bw[mm][pm];
                                 if (wv > best) { bi = mm; best = wv; ix = ixv[mm][e]; }
@@ -460,15 +461,24 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
     }
     R *acc = static_cast<R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM + local;
 #pragma unroll
-    for (int pm = 0; pm < kMaxMix; ++pm)
+    for (int pm = 0; pm < MAXM; ++pm)
         if (pm < cj.npar) store_cells<R, kCpt>(acc + (size_t)(cj.acc_plane + pm) * HW, n, accv[pm]);
 }
 
 void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hipStream_t s)
 {
     if (ncjobs == 0 || p.quad_per_frame == 0) return;
-    if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2>), dim3((unsigned)((p.quad_per_frame * 2 + 255) / 256), ncjobs, nframes), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_dp_combine<float, 4>), dim3((unsigned)((p.quad_per_frame + 255) / 256), ncjobs, nframes), dim3(256), 0, s, p);
+    const dim3 g2((unsigned)((p.quad_per_frame * 2 + 255) / 256), ncjobs, nframes), g4((unsigned)((p.quad_per_frame + 255) / 256), ncjobs, nframes);
+#define PBD_COMBINE(M)                                                                      \
+    do {                                                                                    \
+        if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2, M>), g2, dim3(256), 0, s, p);   \
+        else hipLaunchKernelGGL((k_dp_combine<float, 4, M>), g4, dim3(256), 0, s, p);        \
+    } while (0)
+    if (p.max_mix <= 2) PBD_COMBINE(2);
+    else if (p.max_mix <= 4) PBD_COMBINE(4);
+    else if (p.max_mix <= 6) PBD_COMBINE(6);
+    else PBD_COMBINE(8);
+#undef PBD_COMBINE
 }
 
 // ---- root: rootv = max over root mixtures of (accumulated score + bias) ----------------------------
