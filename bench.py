@@ -67,8 +67,28 @@ def parse():
     return ap.parse_args()
 
 
+def _spawn_workers(args):
+    """`python bench.py --gpus N` without a launcher: start the N workers ourselves (one process per GPU) as a CHILD
+    `python -m torch.distributed.run ...` -- before this process has imported torch or touched the GPU -- forward its
+    output (rank 0's JSON line goes to the inherited stdout) and exit with its return code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_workers(args))
     import torch
     import torch.distributed as dist
     from partsbaseddetector_amd import _lib, synth
@@ -79,8 +99,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -107,7 +126,9 @@ def main():
 
     # gather payload: [count | cap_g records] per rank; latency-bound (KBs-MBs), ONE collective per step
     from partsbaseddetector_amd import dist as pdist
-    cap_g = 8192
+    # initial gather capacity in records (7.3 MB per rank for the person model); a batch with more candidates than
+    # this makes every rank grow its buffers and repeat the collective once -- it never raises (dist.CandidateGatherer)
+    cap_g = 16384
     dev = torch.device("cuda", local_rank)
 
     gatherer = pdist.CandidateGatherer(stride, cap_g, dev if args.backend == "nccl" else "cpu") if world > 1 else None
@@ -137,10 +158,13 @@ def main():
         ncand = step()
     sync()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        dt = max(float(t.item()) for t in every)          # MAX over ranks
     prof = det.hd.profile_read() if not args.no_profile else {}
 
     if rank == 0:
@@ -291,7 +315,12 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: synthetic person model (26 parts x 6 mixtures = 156 filters "
                                    f"5x5x32), batch of {B} {cols}x{rows} frames per GPU, full HOG+conv+DT/DP+argmin on GPU",
                        "frames_per_gpu_per_step": B, "conv_mode": args.conv_mode, "candidates_last_step": int(ncand),
-                       "parallelism": f"frames sharded over {world} GPU(s), RCCL all_gather of candidates"},
+                       "parallelism": f"frames sharded over {world} GPU(s), RCCL all_gather of candidates",
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": dist.get_backend() if world > 1 else None,
+                       "rank_ms_per_step": [round(v, 3) for v in rank_ms],
+                       "gather": ({"collectives_per_step": gatherer.collectives / max(args.steps + args.warmup, 1),
+                                   "capacity_records": gatherer.cap, "grown": gatherer.grown} if gatherer else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": stage_ms,
             "roofline_all": roof_all,
             ("fast_mode" if args.conv_mode == "exact" else "exact_mode"): other_mode, "agreement": agreement,

@@ -15,8 +15,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpbd_hip.so")
 SOURCES = ["pbd_capi.hip", "pbd_kernels_features.hip", "pbd_kernels_conv.hip", "pbd_kernels_conv_mfma.hip", "pbd_kernels_dp.hip"]
 HEADERS = ["pbd_internal.h", os.path.join("..", "..", "include", "pbd.h")]
-FLAGS = os.environ.get("PBD_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = os.environ.get("PBD_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall"]
+OBJ = os.path.join(CSRC, "build")          # object files (git-ignored); one per source so that they compile in parallel
 
 
 def hipcc() -> str:
@@ -37,7 +38,23 @@ def stale() -> bool:
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(obj)
+        spath = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), hdr_t):
+            continue
+        cmd = [hipcc()] + FLAGS + ["-c", "-o", obj, spath]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

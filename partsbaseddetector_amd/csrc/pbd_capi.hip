@@ -16,7 +16,9 @@
 #include <algorithm>
 #include <memory>
 #include <numeric>
+#include <new>
 #include <set>
+#include <stdexcept>
 
 using namespace pbd;
 
@@ -94,7 +96,7 @@ inline short sat_short_round(float v)
 struct Plan {
     // key
     int kind = 0;   // 0: from image size, 1: from explicit feature-map sizes
-    int rows = 0, cols = 0, cn = 0;
+    int rows = 0, cols = 0;         // the geometry does not depend on the channel count (offsets are in pixels)
     std::vector<int> key_dims;
     // geometry
     int nlevels = 0;
@@ -185,6 +187,7 @@ struct pbd_handle {
     int JGmax = 0;
     int max_mix = 1;                 // largest number of mixtures of any part
     bool filters_set = false;
+    bool bank_matches_model = true;  // false after a setFilters() whose bank no longer covers the model's filter ids
 
     // device model tables
     DevBuf d_wts;                    // real-typed weights
@@ -201,7 +204,7 @@ struct pbd_handle {
     // plans
     std::vector<std::unique_ptr<Plan>> plans;
     Plan *cur = nullptr;
-    int cur_frames = 0;
+    int cur_frames = 0, cur_cn = 3;
     bool have_features = false, have_resp = false, have_dp = false;
 
     // workspace
@@ -221,16 +224,41 @@ int fail(pbd_handle *h, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (h) h->err = buf; else g_create_error = buf;
+    try {
+        if (h) h->err = buf; else g_create_error = buf;
+    } catch (...) {   // the message itself could not be stored: the status code still goes out
+    }
     return code;
 }
 
 #define HIPCHK(h, expr)                                                                             \
     do {                                                                                            \
         hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess)                                                                       \
-            return fail(h, PBD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        if (e_ != hipSuccess) {                                                                     \
+            (void)hipGetLastError();   /* the error is reported through the status code, not left sticky */ \
+            return fail(h, e_ == hipErrorOutOfMemory ? PBD_ERR_NOMEM : PBD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                 \
+        }                                                                                           \
     } while (0)
+
+// "No exception crosses this ABI" (include/pbd.h): every extern "C" body runs inside guarded().  The
+// reference's errors on this path are CV_Error / bool returns, never process death
+// (src/HOGFeatures.cpp:141-145, src/FileStorageModel.cpp:100-101).
+template <class F>
+int guarded(pbd_handle *h, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(h, PBD_ERR_NOMEM, "out of host memory");
+    } catch (const std::length_error &e) {
+        return fail(h, PBD_ERR_NOMEM, "host allocation too large: %s", e.what());
+    } catch (const std::exception &e) {
+        return fail(h, PBD_ERR_INVALID, "unexpected exception: %s", e.what());
+    } catch (...) {
+        return fail(h, PBD_ERR_INVALID, "unexpected exception");
+    }
+}
 
 struct ProfScope {
     pbd_handle *h; int k; hipStream_t st; hipEvent_t a{}, b{};
@@ -274,7 +302,7 @@ static void cover_level(int l, int rows, int cols, std::vector<ConvTile> *shaped
     }
 }
 
-void finish_plan_tables(Plan &P)
+hipError_t finish_plan_tables(Plan &P)
 {
     // flat row / column lookup and conv tiles over the feature maps
     std::vector<int> row2level, rowoff(P.nlevels + 1, 0), col2level, coloff(P.nlevels + 1, 0);
@@ -316,24 +344,37 @@ void finish_plan_tables(Plan &P)
         tot_c += 64LL * ((mx + 1) / 2);
     }
     P.stk_per_jf = std::max(tot_r, tot_c);
-    (void)P.d_stk_row_off.upload(srow);
-    (void)P.d_stk_col_off.upload(scol);
-    (void)P.d_lv.upload(P.lv);
-    (void)P.d_tiles.upload(tiles);
     std::vector<ConvTile> all;
     for (int k = 0; k < 3; ++k) { P.nshaped[k] = (int)shaped[k].size(); all.insert(all.end(), shaped[k].begin(), shaped[k].end()); }
-    (void)P.d_shaped.upload(all);
-    (void)P.d_row2level.upload(row2level);
-    (void)P.d_rowoff.upload(rowoff);
-    (void)P.d_col2level.upload(col2level);
-    (void)P.d_coloff.upload(coloff);
-    (void)P.d_scales.upload(P.scales);
+    hipError_t e;
+    if ((e = P.d_stk_row_off.upload(srow)) != hipSuccess) return e;
+    if ((e = P.d_stk_col_off.upload(scol)) != hipSuccess) return e;
+    if ((e = P.d_lv.upload(P.lv)) != hipSuccess) return e;
+    if ((e = P.d_tiles.upload(tiles)) != hipSuccess) return e;
+    if ((e = P.d_shaped.upload(all)) != hipSuccess) return e;
+    if ((e = P.d_row2level.upload(row2level)) != hipSuccess) return e;
+    if ((e = P.d_rowoff.upload(rowoff)) != hipSuccess) return e;
+    if ((e = P.d_col2level.upload(col2level)) != hipSuccess) return e;
+    if ((e = P.d_coloff.upload(coloff)) != hipSuccess) return e;
+    return P.d_scales.upload(P.scales);
 }
 
-int get_image_plan(pbd_handle *h, int rows, int cols, int cn, Plan **out)
+// A finished plan joins the cache; the cache holds at most 16 plans and never evicts the plan the handle's
+// staged results refer to (h->cur).
+void cache_plan(pbd_handle *h, std::unique_ptr<Plan> P)
+{
+    h->plans.push_back(std::move(P));
+    while (h->plans.size() > 16) {
+        auto it = h->plans.begin();
+        if (it->get() == h->cur) ++it;
+        h->plans.erase(it);
+    }
+}
+
+int get_image_plan(pbd_handle *h, int rows, int cols, Plan **out)
 {
     for (auto &p : h->plans)
-        if (p->kind == 0 && p->rows == rows && p->cols == cols && p->cn == cn) { *out = p.get(); return PBD_OK; }
+        if (p->kind == 0 && p->rows == rows && p->cols == cols) { *out = p.get(); return PBD_OK; }
     std::vector<int> lr, lc;
     std::vector<float> scales;
     const int n = plan_pyramid(rows, cols, h->sbin, h->interval, lr, lc, scales);
@@ -341,7 +382,7 @@ int get_image_plan(pbd_handle *h, int rows, int cols, int cn, Plan **out)
         return fail(h, PBD_ERR_INVALID, "frame %dx%d too small for sbin %d / interval %d (nscales %d)", rows, cols,
                     h->sbin, h->interval, n);
     auto P = std::make_unique<Plan>();
-    P->kind = 0; P->rows = rows; P->cols = cols; P->cn = cn;
+    P->kind = 0; P->rows = rows; P->cols = cols;
     P->nlevels = n; P->scales = scales; P->interval = h->interval;
     P->lv.resize(n);
     std::vector<ResizeTabX> tabx;
@@ -388,7 +429,7 @@ int get_image_plan(pbd_handle *h, int rows, int cols, int cn, Plan **out)
     if (P->npix_resized == 0) P->npix_resized = pix;
     HIPCHK(h, P->d_tabx.upload(tabx));
     HIPCHK(h, P->d_taby.upload(taby));
-    finish_plan_tables(*P);
+    HIPCHK(h, finish_plan_tables(*P));
     // HOG coordinate table grows with the largest frame seen
     const int need = std::max(rows, cols) + 4 * h->sbin + 8;
     if (need > h->coord_n) {
@@ -418,8 +459,7 @@ int get_image_plan(pbd_handle *h, int rows, int cols, int cn, Plan **out)
         h->coord_n = need;
     }
     *out = P.get();
-    h->plans.push_back(std::move(P));
-    if (h->plans.size() > 16) h->plans.erase(h->plans.begin());
+    cache_plan(h, std::move(P));
     return PBD_OK;
 }
 
@@ -446,10 +486,9 @@ int get_dims_plan(pbd_handle *h, int nlevels, const int *rows, const int *cols, 
         cell += (long long)rows[l] * cols[l];
     }
     P->cell_per_frame = cell;
-    finish_plan_tables(*P);
+    HIPCHK(h, finish_plan_tables(*P));
     *out = P.get();
-    h->plans.push_back(std::move(P));
-    if (h->plans.size() > 16) h->plans.erase(h->plans.begin());
+    cache_plan(h, std::move(P));
     return PBD_OK;
 }
 
@@ -534,6 +573,27 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
 int upload_filters(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize)
 {
     return h->f64 ? upload_filters_t<double>(h, nfilters, filters, ksize) : upload_filters_t<float>(h, nfilters, filters, ksize);
+}
+
+// After pbd_conv_set_filters replaced the bank: the model tables built by build_model index response planes by
+// filter id, and the part boxes of argmin use the filter size (include/Parts.hpp:185-187), so both are re-checked /
+// rebuilt against the new bank.  A bank that does not cover the model's ids leaves the convolution engine usable on
+// its own (IConvolutionEngine::pdf) and makes the model-dependent calls fail with PBD_ERR_STATE.
+int revalidate_bank(pbd_handle *h)
+{
+    h->bank_matches_model = true;
+    for (int f : h->filterid)
+        if (f < 0 || f >= h->F) { h->bank_matches_model = false; return PBD_OK; }
+    for (int c = 0; c < h->NC; ++c) {
+        const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
+        for (int p = 0; p < np; ++p) {
+            PartWalk &w = h->walk[h->walk_off[c] + p];
+            const int K = h->mix_offset[p0 + p + 1] - h->mix_offset[p0 + p];
+            for (int mm = 0; mm < K; ++mm) w.ksize[mm] = h->filter_ksize[h->filterid[h->mix_offset[p0 + p] + mm]];
+        }
+    }
+    HIPCHK(h, h->d_walk.upload(h->walk));
+    return PBD_OK;
 }
 
 int build_model(pbd_handle *h, const pbd_model *m)
@@ -704,9 +764,9 @@ int build_model(pbd_handle *h, const pbd_model *m)
 // ---- stages --------------------------------------------------------------------------------------
 // alloc_* size the grow-only workspace for `nframes`; launch_* enqueue the kernels for frames
 // [f0, f0+nb) on stream `st` (no allocation, no synchronisation inside).
-int alloc_features(pbd_handle *h, Plan &P, int nframes)
+int alloc_features(pbd_handle *h, Plan &P, int nframes, int cn)
 {
-    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * P.cn + 4));   // +4: pixels are read as one 32-bit load
+    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * cn + 4));   // +4: pixels are read as one 32-bit load
     HIPCHK(h, h->gmag.ensure((size_t)nframes * P.pix_per_frame * h->rs));
     HIPCHK(h, h->gori.ensure((size_t)nframes * P.pix_per_frame));
     HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * h->rs));
@@ -715,9 +775,8 @@ int alloc_features(pbd_handle *h, Plan &P, int nframes)
     return PBD_OK;
 }
 
-void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int f0, int nb, hipStream_t st)
+void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int cn, int f0, int nb, hipStream_t st)
 {
-    const int cn = P.cn;
     PyrParams pp{};
     pp.lv = P.d_lv.d; pp.nlevels = P.nlevels; pp.interval = std::min(P.interval, P.nlevels); pp.cn = cn; pp.frame0 = f0;
     pp.pix_per_frame = P.pix_per_frame; pp.pyr = h->pyr.as<uint8_t>(); pp.frames = static_cast<const uint8_t *>(d_frames);
@@ -781,7 +840,10 @@ int dp_chunk_frames(pbd_handle *h, Plan &P, int want)
 {
     const size_t per_frame = (size_t)P.cell_per_frame * std::max(h->JGmax, 1);
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
-    const size_t budget = (size_t)8 << 30;   // bytes of scratch per chunk (12 B / cell-job + 16 B / two stack entries)
+    // bytes of scratch per chunk (12 B / cell-job + 16 B / two stack entries); PBD_DP_BUDGET_MB lets the tests
+    // force several chunks on a small batch
+    const char *env_budget = getenv("PBD_DP_BUDGET_MB");
+    const size_t budget = env_budget && atoll(env_budget) > 0 ? (size_t)atoll(env_budget) << 20 : (size_t)8 << 30;
     int chunk = std::max(want, 1);
     while (chunk > 1 && (per_frame * (6 + 2 * h->rs) + stk_per_frame * (h->f64 ? kStkPairF64 : kStkPairF32)) * chunk > budget) chunk = (chunk + 1) / 2;
     return chunk;
@@ -836,11 +898,11 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
 }
 
 // single-stream wrappers used by the staged entry points
-int run_features(pbd_handle *h, Plan &P, int nframes)
+int run_features(pbd_handle *h, Plan &P, int nframes, int cn)
 {
-    int rc = alloc_features(h, P, nframes);
+    int rc = alloc_features(h, P, nframes, cn);
     if (rc != PBD_OK) return rc;
-    launch_features(h, P, h->frames.p, 0, nframes, h->stream);
+    launch_features(h, P, h->frames.p, cn, 0, nframes, h->stream);
     HIPCHK(h, hipGetLastError());
     h->have_features = true;
     return PBD_OK;
@@ -931,10 +993,12 @@ int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, in
     if (nframes < 1 || nframes > h->cfg.max_batch)
         return fail(h, PBD_ERR_INVALID, "nframes %d outside 1..max_batch %d", nframes, h->cfg.max_batch);
     if (cn != 1 && cn != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", cn);
+    if (!h->bank_matches_model)
+        return fail(h, PBD_ERR_STATE, "the filter bank set by setFilters() (%d filters) does not cover the model's filter ids", h->F);
     Plan *P = nullptr;
-    int rc = get_image_plan(h, rows, cols, cn, &P);
+    int rc = get_image_plan(h, rows, cols, &P);
     if (rc != PBD_OK) return rc;
-    h->cur = P; h->cur_frames = nframes;
+    h->cur = P; h->cur_frames = nframes; h->cur_cn = cn;
     h->have_features = h->have_resp = h->have_dp = false;
     // Software pipeline over chunks of frames: features + convolution of chunk c run on `stream`, the
     // dynamic program of chunk c-1 on `stream2`.  The convolution is VALU-bound and the distance
@@ -945,7 +1009,7 @@ int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, in
     static const int env_chunks = getenv("PBD_PIPELINE_CHUNKS") ? atoi(getenv("PBD_PIPELINE_CHUNKS")) : 1;
     const int want = env_chunks > 1 ? (nframes + env_chunks - 1) / env_chunks : nframes;
     const int chunk = dp_chunk_frames(h, *P, want);
-    if ((rc = alloc_features(h, *P, nframes)) != PBD_OK) return rc;
+    if ((rc = alloc_features(h, *P, nframes, cn)) != PBD_OK) return rc;
     if ((rc = alloc_conv(h, *P, nframes)) != PBD_OK) return rc;
     if ((rc = alloc_dp(h, *P, nframes, chunk)) != PBD_OK) return rc;
     const int nchunks = (nframes + chunk - 1) / chunk;
@@ -962,7 +1026,7 @@ int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, in
     }
     for (int c = 0; c < nchunks; ++c) {
         const int f0 = c * chunk, nb = std::min(chunk, nframes - f0);
-        launch_features(h, *P, d_frames, f0, nb, h->stream);
+        launch_features(h, *P, d_frames, cn, f0, nb, h->stream);
         launch_conv_stage(h, *P, f0, nb, h->stream);
         if (two) {
             HIPCHK(h, hipEventRecord(h->chunk_events[c], h->stream));
@@ -1002,61 +1066,77 @@ int pbd_debug_conv_occupancy(int nw) { return conv_occupancy(nw); }
 // the convolution's tile cover of one rows x cols level (host-only, no GPU needed): out[i] = {shape, y0, x0}
 int pbd_debug_cover_level(int rows, int cols, int *out, int capacity)
 {
-    std::vector<ConvTile> shaped[3];
-    cover_level(0, rows, cols, shaped);
-    int n = 0;
-    for (int k = 0; k < 3; ++k)
-        for (const ConvTile &t : shaped[k]) {
-            if (n < capacity) { out[3 * n] = k; out[3 * n + 1] = t.y0; out[3 * n + 2] = t.x0; }
-            ++n;
-        }
-    return n;
+    return guarded(nullptr, [&]() -> int {
+        std::vector<ConvTile> shaped[3];
+        cover_level(0, rows, cols, shaped);
+        int n = 0;
+        for (int k = 0; k < 3; ++k)
+            for (const ConvTile &t : shaped[k]) {
+                if (n < capacity) { out[3 * n] = k; out[3 * n + 1] = t.y0; out[3 * n + 2] = t.x0; }
+                ++n;
+            }
+        return n;
+    });
+}
+
+// runs a body that throws inside the ABI guard (host-only): 0 = std::bad_alloc, 1 = std::length_error from an absurd
+// std::vector size, 2 = another std::exception; returns the status code the guard produced
+int pbd_debug_guard_selftest(int kind)
+{
+    return guarded(nullptr, [&]() -> int {
+        if (kind == 0) throw std::bad_alloc();
+        if (kind == 1) { std::vector<int32_t> v; v.resize(v.max_size() + (size_t)1); return (int)v.size(); }
+        if (kind == 2) throw std::runtime_error("selftest");
+        return PBD_OK;
+    });
 }
 
 const char *pbd_last_error(const pbd_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int pbd_create(const pbd_model *model, const pbd_config *config, pbd_handle **out)
 {
-    if (!model || !config || !out) return fail(nullptr, PBD_ERR_INVALID, "null argument");
-    *out = nullptr;
-    if (config->real_type != PBD_REAL_F32 && config->real_type != PBD_REAL_F64)
-        return fail(nullptr, PBD_ERR_UNSUPPORTED, "real_type %d: PBD_REAL_F32 or PBD_REAL_F64", config->real_type);
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev < 1)
-        return fail(nullptr, PBD_ERR_HIP, "no HIP device available (%s); this library has no CPU path",
-                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-    if (config->device < 0 || config->device >= ndev) return fail(nullptr, PBD_ERR_INVALID, "device %d of %d", config->device, ndev);
-    e = hipSetDevice(config->device);
-    if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
-    auto h = std::make_unique<pbd_handle>();
-    h->cfg = *config;
-    h->f64 = config->real_type == PBD_REAL_F64;
-    h->rs = h->f64 ? sizeof(double) : sizeof(float);
-    if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
-    if (h->cfg.max_candidates < 1) h->cfg.max_candidates = 65536;
-    if (config->stream) {
-        h->stream = reinterpret_cast<hipStream_t>(config->stream);
-    } else {
-        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    return guarded(nullptr, [&]() -> int {
+        if (!model || !config || !out) return fail(nullptr, PBD_ERR_INVALID, "null argument");
+        *out = nullptr;
+        if (config->real_type != PBD_REAL_F32 && config->real_type != PBD_REAL_F64)
+            return fail(nullptr, PBD_ERR_UNSUPPORTED, "real_type %d: PBD_REAL_F32 or PBD_REAL_F64", config->real_type);
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev < 1)
+            return fail(nullptr, PBD_ERR_HIP, "no HIP device available (%s); this library has no CPU path",
+                        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        if (config->device < 0 || config->device >= ndev) return fail(nullptr, PBD_ERR_INVALID, "device %d of %d", config->device, ndev);
+        e = hipSetDevice(config->device);
+        if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+        std::unique_ptr<pbd_handle, void (*)(pbd_handle *)> h(new pbd_handle, pbd_destroy);   // releases device memory on every exit
+        h->cfg = *config;
+        h->f64 = config->real_type == PBD_REAL_F64;
+        h->rs = h->f64 ? sizeof(double) : sizeof(float);
+        if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
+        if (h->cfg.max_candidates < 1) h->cfg.max_candidates = 65536;
+        if (config->stream) {
+            h->stream = reinterpret_cast<hipStream_t>(config->stream);
+        } else {
+            e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+            h->own_stream = true;
+        }
+        e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
         if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-        h->own_stream = true;
-    }
-    e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
-    if (e != hipSuccess) return fail(nullptr, PBD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-    int rc = build_model(h.get(), model);
-    if (rc != PBD_OK) {
-        g_create_error = h->err;
-        pbd_destroy(h.release());
-        return rc;
-    }
-    *out = h.release();
-    return PBD_OK;
+        int rc = build_model(h.get(), model);
+        if (rc != PBD_OK) {
+            g_create_error = h->err;
+            return rc;
+        }
+        *out = h.release();
+        return PBD_OK;
+    });
 }
 
 void pbd_destroy(pbd_handle *h)
 {
     if (!h) return;
+    try {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
@@ -1072,6 +1152,8 @@ void pbd_destroy(pbd_handle *h)
     for (auto &g : h->groups) { g.d_jobs.release(); g.d_childs.release(); g.d_cjobs.release(); }
     h->plans.clear();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    } catch (...) {
+    }
     delete h;
 }
 
@@ -1089,147 +1171,167 @@ int pbd_ptr_slot(const pbd_handle *h, int component, int part)
 int pbd_pyramid_plan(pbd_handle *h, int rows, int cols, int *nlevels, int *img_rows, int *img_cols, int *feat_rows,
                      int *feat_cols, float *scales)
 {
-    if (!h || !nlevels) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    Plan *P = nullptr;
-    int rc = get_image_plan(h, rows, cols, 3, &P);
-    if (rc != PBD_OK) return rc;
-    *nlevels = P->nlevels;
-    for (int l = 0; l < P->nlevels; ++l) {
-        if (img_rows) img_rows[l] = P->lv[l].img_rows;
-        if (img_cols) img_cols[l] = P->lv[l].img_cols;
-        if (feat_rows) feat_rows[l] = P->lv[l].rows;
-        if (feat_cols) feat_cols[l] = P->lv[l].cols;
-        if (scales) scales[l] = P->scales[l];
-    }
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h || !nlevels) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        Plan *P = nullptr;
+        int rc = get_image_plan(h, rows, cols, &P);
+        if (rc != PBD_OK) return rc;
+        *nlevels = P->nlevels;
+        for (int l = 0; l < P->nlevels; ++l) {
+            if (img_rows) img_rows[l] = P->lv[l].img_rows;
+            if (img_cols) img_cols[l] = P->lv[l].img_cols;
+            if (feat_rows) feat_rows[l] = P->lv[l].rows;
+            if (feat_cols) feat_cols[l] = P->lv[l].cols;
+            if (scales) scales[l] = P->scales[l];
+        }
+        return PBD_OK;
+    });
 }
 
 int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int channels, size_t stride_bytes,
                          int depth_code, void *const *feat)
 {
-    if (!h || !img || !feat) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    if (depth_code != 0) return fail(h, PBD_ERR_UNSUPPORTED, "image depth code %d: only 8-bit unsigned is supported", depth_code);
-    if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
-    Plan *P = nullptr;
-    int rc = get_image_plan(h, rows, cols, channels, &P);
-    if (rc != PBD_OK) return rc;
-    if ((rc = upload_frames(h, 1, &img, rows, cols, channels, stride_bytes)) != PBD_OK) return rc;
-    h->cur = P; h->cur_frames = 1;
-    h->have_features = h->have_resp = h->have_dp = false;
-    if ((rc = run_features(h, *P, 1)) != PBD_OK) return rc;
-    for (int l = 0; l < P->nlevels; ++l) {
-        const LevelDesc &d = P->lv[l];
-        const size_t n = (size_t)d.rows * d.cols * 32;
-        if (n && feat[l])
-            HIPCHK(h, hipMemcpyAsync(feat[l], h->feat.as<char>() + (size_t)d.cell_off * 32 * h->rs, n * h->rs,
-                                     hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h || !img || !feat) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (depth_code != 0) return fail(h, PBD_ERR_UNSUPPORTED, "image depth code %d: only 8-bit unsigned is supported", depth_code);
+        if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
+        Plan *P = nullptr;
+        int rc = get_image_plan(h, rows, cols, &P);
+        if (rc != PBD_OK) return rc;
+        if ((rc = upload_frames(h, 1, &img, rows, cols, channels, stride_bytes)) != PBD_OK) return rc;
+        h->cur = P; h->cur_frames = 1; h->cur_cn = channels;
+        h->have_features = h->have_resp = h->have_dp = false;
+        if ((rc = run_features(h, *P, 1, channels)) != PBD_OK) return rc;
+        for (int l = 0; l < P->nlevels; ++l) {
+            const LevelDesc &d = P->lv[l];
+            const size_t n = (size_t)d.rows * d.cols * 32;
+            if (n && feat[l])
+                HIPCHK(h, hipMemcpyAsync(feat[l], h->feat.as<char>() + (size_t)d.cell_off * 32 * h->rs, n * h->rs,
+                                         hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PBD_OK;
+    });
 }
 
 int pbd_get_pyramid_image(pbd_handle *h, int frame, int level, uint8_t *dst)
 {
-    if (!h || !dst) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    if (!h->cur || h->cur->kind != 0 || !h->have_features) return fail(h, PBD_ERR_STATE, "no pyramid has been computed");
-    Plan &P = *h->cur;
-    if (frame < 0 || frame >= h->cur_frames || level < 0 || level >= P.nlevels) return fail(h, PBD_ERR_INVALID, "frame/level out of range");
-    const LevelDesc &d = P.lv[level];
-    HIPCHK(h, hipMemcpyAsync(dst, h->pyr.as<uint8_t>() + ((size_t)frame * P.pix_per_frame + d.img_off) * P.cn,
-                             (size_t)d.img_rows * d.img_cols * P.cn, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h || !dst) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (!h->cur || h->cur->kind != 0 || !h->have_features) return fail(h, PBD_ERR_STATE, "no pyramid has been computed");
+        Plan &P = *h->cur;
+        if (frame < 0 || frame >= h->cur_frames || level < 0 || level >= P.nlevels) return fail(h, PBD_ERR_INVALID, "frame/level out of range");
+        const LevelDesc &d = P.lv[level];
+        HIPCHK(h, hipMemcpyAsync(dst, h->pyr.as<uint8_t>() + ((size_t)frame * P.pix_per_frame + d.img_off) * h->cur_cn,
+                                 (size_t)d.img_rows * d.img_cols * h->cur_cn, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PBD_OK;
+    });
 }
 
 int pbd_conv_set_filters(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize)
 {
-    if (!h || !filters || !ksize) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return upload_filters(h, nfilters, filters, ksize);
+    return guarded(h, [&]() -> int {
+        if (!h || !filters || !ksize) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
+        const int rc = upload_filters(h, nfilters, filters, ksize);
+        if (rc != PBD_OK) return rc;
+        h->have_resp = h->have_dp = false;   // staged results of the old bank are gone
+        return revalidate_bank(h);
+    });
 }
 
 int pbd_conv_pdf(pbd_handle *h, int nlevels, const void *const *feat, const int *rows, const int *cols, void *const *resp)
 {
-    if (!h || !feat || !rows || !cols || !resp) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    Plan *P = nullptr;
-    int rc = get_dims_plan(h, nlevels, rows, cols, &P);
-    if (rc != PBD_OK) return rc;
-    HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)P->cell_per_frame * 32 * h->rs, 16)));
-    for (int l = 0; l < nlevels; ++l) {
-        const size_t n = (size_t)rows[l] * cols[l] * 32;
-        if (n) HIPCHK(h, hipMemcpyAsync(h->feat.as<char>() + (size_t)P->lv[l].cell_off * 32 * h->rs, feat[l], n * h->rs,
-                                        hipMemcpyHostToDevice, h->stream));
-    }
-    h->cur = P; h->cur_frames = 1; h->have_features = true; h->have_resp = h->have_dp = false;
-    if ((rc = run_conv(h, *P, 1)) != PBD_OK) return rc;
-    for (int l = 0; l < nlevels; ++l) {
-        const size_t n = (size_t)rows[l] * cols[l] * h->F;
-        if (n) HIPCHK(h, hipMemcpyAsync(resp[l], h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->rs, n * h->rs,
-                                        hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h || !feat || !rows || !cols || !resp) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        Plan *P = nullptr;
+        int rc = get_dims_plan(h, nlevels, rows, cols, &P);
+        if (rc != PBD_OK) return rc;
+        HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)P->cell_per_frame * 32 * h->rs, 16)));
+        for (int l = 0; l < nlevels; ++l) {
+            const size_t n = (size_t)rows[l] * cols[l] * 32;
+            if (n) HIPCHK(h, hipMemcpyAsync(h->feat.as<char>() + (size_t)P->lv[l].cell_off * 32 * h->rs, feat[l], n * h->rs,
+                                            hipMemcpyHostToDevice, h->stream));
+        }
+        h->cur = P; h->cur_frames = 1; h->have_features = true; h->have_resp = h->have_dp = false;
+        if ((rc = run_conv(h, *P, 1)) != PBD_OK) return rc;
+        for (int l = 0; l < nlevels; ++l) {
+            const size_t n = (size_t)rows[l] * cols[l] * h->F;
+            if (n) HIPCHK(h, hipMemcpyAsync(resp[l], h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->rs, n * h->rs,
+                                            hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PBD_OK;
+    });
 }
 
 int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, const void *const *resp, int32_t *const *Ix,
                int32_t *const *Iy, int32_t *const *Ik, void *const *rootv, int32_t *const *rooti)
 {
-    if (!h || !rows || !cols || !resp) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    Plan *P = nullptr;
-    int rc = get_dims_plan(h, nlevels, rows, cols, &P);
-    if (rc != PBD_OK) return rc;
-    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)P->cell_per_frame * h->F * h->rs, 16)));
-    for (int l = 0; l < nlevels; ++l) {
-        const size_t n = (size_t)rows[l] * cols[l] * h->F;
-        if (n) HIPCHK(h, hipMemcpyAsync(h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->rs, resp[l], n * h->rs,
-                                        hipMemcpyHostToDevice, h->stream));
-    }
-    h->cur = P; h->cur_frames = 1; h->have_resp = true; h->have_dp = false;
-    if ((rc = run_dp(h, *P, 1)) != PBD_OK) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::vector<int16_t> t16;
-    std::vector<uint8_t> t8;
-    for (int l = 0; l < nlevels; ++l) {
-        const size_t hw = (size_t)rows[l] * cols[l];
-        if (!hw) continue;
-        const size_t n = hw * h->NS, off = (size_t)P->lv[l].cell_off * h->NS;
-        if (n) {
-            t16.resize(n); t8.resize(n);
-            if (Ix && Ix[l]) {
-                HIPCHK(h, hipMemcpy(t16.data(), h->Ix.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < n; ++i) Ix[l][i] = t16[i];
-            }
-            if (Iy && Iy[l]) {
-                HIPCHK(h, hipMemcpy(t16.data(), h->Iy.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < n; ++i) Iy[l][i] = t16[i];
-            }
-            if (Ik && Ik[l]) {
-                HIPCHK(h, hipMemcpy(t8.data(), h->Ik.as<uint8_t>() + off, n, hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < n; ++i) Ik[l][i] = t8[i];
-            }
+    return guarded(h, [&]() -> int {
+        if (!h || !rows || !cols || !resp) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        Plan *P = nullptr;
+        if (!h->bank_matches_model)
+            return fail(h, PBD_ERR_STATE, "the filter bank set by setFilters() (%d filters) does not cover the model's filter ids", h->F);
+        int rc = get_dims_plan(h, nlevels, rows, cols, &P);
+        if (rc != PBD_OK) return rc;
+        HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)P->cell_per_frame * h->F * h->rs, 16)));
+        for (int l = 0; l < nlevels; ++l) {
+            const size_t n = (size_t)rows[l] * cols[l] * h->F;
+            if (n) HIPCHK(h, hipMemcpyAsync(h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->rs, resp[l], n * h->rs,
+                                            hipMemcpyHostToDevice, h->stream));
         }
-        const size_t roff = (size_t)P->lv[l].cell_off * h->NC;
-        if (rootv && rootv[l]) HIPCHK(h, hipMemcpy(rootv[l], h->rootv.as<char>() + roff * h->rs, hw * h->NC * h->rs, hipMemcpyDeviceToHost));
-        if (rooti && rooti[l]) HIPCHK(h, hipMemcpy(rooti[l], h->rooti.as<int>() + roff, hw * h->NC * sizeof(int), hipMemcpyDeviceToHost));
-    }
-    return PBD_OK;
+        h->cur = P; h->cur_frames = 1; h->have_resp = true; h->have_dp = false;
+        if ((rc = run_dp(h, *P, 1)) != PBD_OK) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<int16_t> t16;
+        std::vector<uint8_t> t8;
+        for (int l = 0; l < nlevels; ++l) {
+            const size_t hw = (size_t)rows[l] * cols[l];
+            if (!hw) continue;
+            const size_t n = hw * h->NS, off = (size_t)P->lv[l].cell_off * h->NS;
+            if (n) {
+                t16.resize(n); t8.resize(n);
+                if (Ix && Ix[l]) {
+                    HIPCHK(h, hipMemcpy(t16.data(), h->Ix.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < n; ++i) Ix[l][i] = t16[i];
+                }
+                if (Iy && Iy[l]) {
+                    HIPCHK(h, hipMemcpy(t16.data(), h->Iy.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < n; ++i) Iy[l][i] = t16[i];
+                }
+                if (Ik && Ik[l]) {
+                    HIPCHK(h, hipMemcpy(t8.data(), h->Ik.as<uint8_t>() + off, n, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < n; ++i) Ik[l][i] = t8[i];
+                }
+            }
+            const size_t roff = (size_t)P->lv[l].cell_off * h->NC;
+            if (rootv && rootv[l]) HIPCHK(h, hipMemcpy(rootv[l], h->rootv.as<char>() + roff * h->rs, hw * h->NC * h->rs, hipMemcpyDeviceToHost));
+            if (rooti && rooti[l]) HIPCHK(h, hipMemcpy(rooti[l], h->rooti.as<int>() + roff, hw * h->NC * sizeof(int), hipMemcpyDeviceToHost));
+        }
+        return PBD_OK;
+    });
 }
 
 int pbd_dp_argmin(pbd_handle *h, const float *scales, int32_t *cand, int capacity, int *ncand)
 {
-    if (!h || !scales || !cand || !ncand) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    if (!h->cur || !h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
-    Plan &P = *h->cur;
-    HIPCHK(h, h->scales_tmp.ensure(sizeof(float) * PBD_MAX_LEVELS));
-    HIPCHK(h, hipMemcpyAsync(h->scales_tmp.p, scales, sizeof(float) * P.nlevels, hipMemcpyHostToDevice, h->stream));
-    return run_argmin(h, P, h->cur_frames, h->scales_tmp.as<float>(), cand, capacity, ncand);
+    return guarded(h, [&]() -> int {
+        if (!h || !scales || !cand || !ncand) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (!h->cur || !h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
+        Plan &P = *h->cur;
+        HIPCHK(h, h->scales_tmp.ensure(sizeof(float) * PBD_MAX_LEVELS));
+        HIPCHK(h, hipMemcpyAsync(h->scales_tmp.p, scales, sizeof(float) * P.nlevels, hipMemcpyHostToDevice, h->stream));
+        return run_argmin(h, P, h->cur_frames, h->scales_tmp.as<float>(), cand, capacity, ncand);
+    });
 }
 
 int pbd_detect(pbd_handle *h, const void *img, int rows, int cols, int channels, size_t stride_bytes, int32_t *cand,
@@ -1241,77 +1343,89 @@ int pbd_detect(pbd_handle *h, const void *img, int rows, int cols, int channels,
 int pbd_detect_batch(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int channels,
                      size_t stride_bytes, int32_t *cand, int capacity, int *ncand)
 {
-    if (!h || !imgs || !cand || !ncand) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    if (nframes < 1 || nframes > h->cfg.max_batch)
-        return fail(h, PBD_ERR_INVALID, "nframes %d outside 1..max_batch %d", nframes, h->cfg.max_batch);
-    if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
-    int rc = upload_frames(h, nframes, imgs, rows, cols, channels, stride_bytes);
-    if (rc != PBD_OK) return rc;
-    return detect_device(h, nframes, h->frames.p, rows, cols, channels, cand, capacity, ncand);
+    return guarded(h, [&]() -> int {
+        if (!h || !imgs || !cand || !ncand) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (nframes < 1 || nframes > h->cfg.max_batch)
+            return fail(h, PBD_ERR_INVALID, "nframes %d outside 1..max_batch %d", nframes, h->cfg.max_batch);
+        if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
+        int rc = upload_frames(h, nframes, imgs, rows, cols, channels, stride_bytes);
+        if (rc != PBD_OK) return rc;
+        return detect_device(h, nframes, h->frames.p, rows, cols, channels, cand, capacity, ncand);
+    });
 }
 
 int pbd_detect_batch_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels,
                             int32_t *cand, int capacity, int *ncand)
 {
-    if (!h || !d_frames) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    return detect_device(h, nframes, d_frames, rows, cols, channels, cand, capacity, ncand);
+    return guarded(h, [&]() -> int {
+        if (!h || !d_frames) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        return detect_device(h, nframes, d_frames, rows, cols, channels, cand, capacity, ncand);
+    });
 }
 
 int pbd_get_stage(pbd_handle *h, int stage, int frame, int level, void *dst, size_t dst_bytes)
 {
-    if (!h || !dst) return PBD_ERR_INVALID;
-    (void)hipSetDevice(h->cfg.device);
-    if (!h->cur) return fail(h, PBD_ERR_STATE, "nothing has been computed");
-    Plan &P = *h->cur;
-    if (frame < 0 || frame >= h->cur_frames || level < 0 || level >= P.nlevels) return fail(h, PBD_ERR_INVALID, "frame/level out of range");
-    const LevelDesc &d = P.lv[level];
-    const size_t hw = (size_t)d.rows * d.cols, cpf = (size_t)P.cell_per_frame;
-    const void *src = nullptr;
-    size_t bytes = 0;
-    switch (stage) {
-    case PBD_STAGE_FEATURES:
-        if (!h->have_features) return fail(h, PBD_ERR_STATE, "features not computed");
-        src = h->feat.as<char>() + ((size_t)frame * cpf + d.cell_off) * 32 * h->rs; bytes = hw * 32 * h->rs; break;
-    case PBD_STAGE_RESPONSES:
-        if (!h->have_resp) return fail(h, PBD_ERR_STATE, "responses not computed");
-        src = h->resp.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->F * h->rs; bytes = hw * h->F * h->rs; break;
-    case PBD_STAGE_ROOTV:
-        if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
-        src = h->rootv.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->NC * h->rs; bytes = hw * h->NC * h->rs; break;
-    case PBD_STAGE_ROOTI:
-        if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
-        src = h->rooti.as<int>() + ((size_t)frame * cpf + d.cell_off) * h->NC; bytes = hw * h->NC * sizeof(int); break;
-    default: return fail(h, PBD_ERR_INVALID, "unknown stage %d", stage);
-    }
-    if (dst_bytes < bytes) return fail(h, PBD_ERR_INVALID, "destination holds %zu bytes, need %zu", dst_bytes, bytes);
-    if (bytes) HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h || !dst) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (!h->cur) return fail(h, PBD_ERR_STATE, "nothing has been computed");
+        Plan &P = *h->cur;
+        if (frame < 0 || frame >= h->cur_frames || level < 0 || level >= P.nlevels) return fail(h, PBD_ERR_INVALID, "frame/level out of range");
+        const LevelDesc &d = P.lv[level];
+        const size_t hw = (size_t)d.rows * d.cols, cpf = (size_t)P.cell_per_frame;
+        const void *src = nullptr;
+        size_t bytes = 0;
+        switch (stage) {
+        case PBD_STAGE_FEATURES:
+            if (!h->have_features) return fail(h, PBD_ERR_STATE, "features not computed");
+            src = h->feat.as<char>() + ((size_t)frame * cpf + d.cell_off) * 32 * h->rs; bytes = hw * 32 * h->rs; break;
+        case PBD_STAGE_RESPONSES:
+            if (!h->have_resp) return fail(h, PBD_ERR_STATE, "responses not computed");
+            src = h->resp.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->F * h->rs; bytes = hw * h->F * h->rs; break;
+        case PBD_STAGE_ROOTV:
+            if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
+            src = h->rootv.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->NC * h->rs; bytes = hw * h->NC * h->rs; break;
+        case PBD_STAGE_ROOTI:
+            if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
+            src = h->rooti.as<int>() + ((size_t)frame * cpf + d.cell_off) * h->NC; bytes = hw * h->NC * sizeof(int); break;
+        default: return fail(h, PBD_ERR_INVALID, "unknown stage %d", stage);
+        }
+        if (dst_bytes < bytes) return fail(h, PBD_ERR_INVALID, "destination holds %zu bytes, need %zu", dst_bytes, bytes);
+        if (bytes) HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PBD_OK;
+    });
 }
 
 int pbd_profile_enable(pbd_handle *h, int on)
 {
-    if (!h) return PBD_ERR_INVALID;
-    h->prof.flush();
-    h->prof.on = on != 0;
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return PBD_ERR_INVALID;
+        h->prof.flush();
+        h->prof.on = on != 0;
+        return PBD_OK;
+    });
 }
 int pbd_profile_reset(pbd_handle *h)
 {
-    if (!h) return PBD_ERR_INVALID;
-    h->prof.flush();
-    for (int k = 0; k < PBD_K_COUNT; ++k) { h->prof.total[k] = 0; h->prof.launches[k] = 0; }
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return PBD_ERR_INVALID;
+        h->prof.flush();
+        for (int k = 0; k < PBD_K_COUNT; ++k) { h->prof.total[k] = 0; h->prof.launches[k] = 0; }
+        return PBD_OK;
+    });
 }
 int pbd_profile_read(pbd_handle *h, int k, double *total_ms, int *launches)
 {
-    if (!h || k < 0 || k >= PBD_K_COUNT) return PBD_ERR_INVALID;
-    h->prof.flush();
-    if (total_ms) *total_ms = h->prof.total[k];
-    if (launches) *launches = h->prof.launches[k];
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h || k < 0 || k >= PBD_K_COUNT) return PBD_ERR_INVALID;
+        h->prof.flush();
+        if (total_ms) *total_ms = h->prof.total[k];
+        if (launches) *launches = h->prof.launches[k];
+        return PBD_OK;
+    });
 }
 const char *pbd_kernel_name(int k)
 {
@@ -1321,10 +1435,12 @@ const char *pbd_kernel_name(int k)
 }
 int pbd_synchronize(pbd_handle *h)
 {
-    if (!h) return PBD_ERR_INVALID;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
-    return PBD_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return PBD_ERR_INVALID;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
+        return PBD_OK;
+    });
 }
 
 }  // extern "C"

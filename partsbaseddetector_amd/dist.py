@@ -2,9 +2,15 @@
 collective except ONE gather of candidate lists per batch.
 
 The path shards embarrassingly (frames are independent; the model, ~0.5 MB, is replicated), so the only
-exchange is the variable-length candidate list.  Each rank contributes a fixed-capacity record
-`[count | count x stride int32 words | padding]`; `torch.distributed.all_gather` (RCCL over xGMI on the
-GPU box, gloo in the CPU tests) moves it.  The payload is KBs-MBs, i.e. latency-bound.
+exchange is the variable-length candidate list.  Each rank contributes a fixed-size payload
+`[count | records | padding]`; `torch.distributed.all_gather_into_tensor` (RCCL over xGMI on the GPU box,
+gloo in the CPU tests) moves it.  The payload is KBs-MBs, i.e. latency-bound.
+
+Capacity never makes a rank raise before the collective (a rank that raised while the others are inside
+the collective would leave them blocked until the RCCL timeout): word 0 carries the rank's TRUE count,
+every rank enters the collective with the records that fit, every rank reads all counts afterwards, and
+if any count exceeds the capacity all ranks grow their buffers to the same new capacity and repeat the
+collective.  In steady state that is exactly one collective per batch.
 """
 from __future__ import annotations
 
@@ -21,10 +27,12 @@ def shard_range(nframes: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def pack_candidates(buf: np.ndarray, n: int, stride: int, cap: int, frame_offset: int = 0) -> np.ndarray:
-    """[count | records] int32 payload of fixed size 1 + cap*stride; frame ids are made global."""
-    m = min(int(n), cap)
+    """[count | records] int32 payload of fixed size 1 + cap*stride; frame ids are made global.
+    Word 0 is the true count `n`; only min(n, cap) records fit (`unpack_gathered` reports that as an overflow)."""
+    n = int(n)
+    m = min(n, cap)
     out = np.zeros(1 + cap * stride, np.int32)
-    out[0] = m
+    out[0] = n
     if m:
         rec = buf[: m * stride].reshape(m, stride).copy()
         rec[:, 0] += frame_offset
@@ -33,52 +41,95 @@ def pack_candidates(buf: np.ndarray, n: int, stride: int, cap: int, frame_offset
 
 
 def unpack_gathered(payloads: List[np.ndarray], stride: int) -> np.ndarray:
-    """Concatenate the records of every rank (rank order = frame order for contiguous shards)."""
+    """Concatenate the records of every rank (rank order = frame order for contiguous shards).
+    Raises OverflowError if a payload's count exceeds what the payload can hold (never truncates silently)."""
     parts = []
-    for p in payloads:
-        m = int(p[0])
+    for r, p in enumerate(payloads):
+        m, cap = int(p[0]), (len(p) - 1) // stride
+        if m > cap:
+            raise OverflowError(f"rank {r} found {m} candidates, payload capacity {cap}")
         parts.append(p[1:1 + m * stride].reshape(m, stride))
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, stride), np.int32)
+
+
+def _grown(need: int) -> int:
+    """capacity (records) after an overflow: next power of two with 25 % head-room -- every rank computes the same value"""
+    cap = 1024
+    while cap < need + need // 4:
+        cap *= 2
+    return cap
 
 
 class CandidateGatherer:
     """The per-batch gather with its buffers allocated once: a pinned host staging buffer for the payload, one
     device tensor for the send side and one [world, payload] tensor for the receive side (a single
-    ``all_gather_into_tensor``).  ``root_only`` lets the other ranks skip the copy back and the unpacking (the
-    collective itself is still the one all_gather every rank takes part in)."""
+    ``all_gather_into_tensor``).  ``root_only`` lets the other ranks skip the copy back and the unpacking of the
+    records (every rank still takes part in the collective and reads the `world` counts, which is what keeps the
+    grow-on-overflow decision identical on all ranks).
+
+    ``cap`` is the initial capacity in records; size it from the detector's ``max_candidates`` when memory allows
+    -- a too-small value costs one extra collective the first time it overflows, never an error."""
 
     def __init__(self, stride: int, cap: int, device):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.stride, self.cap, self.device = stride, cap, torch.device(device)
+        self.stride, self.device = stride, torch.device(device)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.n = 1 + cap * stride
+        self.collectives = 0          # all_gather calls issued so far (tests / bench: 1 per step in steady state)
+        self.grown = 0                # how often the buffers had to grow
+        self._copy_done = None        # event after the last H2D copy out of host_send (cuda only)
+        self._alloc(max(int(cap), 1))
+
+    def _alloc(self, cap: int):
+        torch = self.torch
+        self.cap = cap
+        self.n = 1 + cap * self.stride
         pin = self.device.type == "cuda"
         self.host_send = torch.zeros(self.n, dtype=torch.int32, pin_memory=pin)
         self.host_recv = torch.zeros(self.world * self.n, dtype=torch.int32, pin_memory=pin)
         self.dev_send = torch.zeros(self.n, dtype=torch.int32, device=self.device)
         self.dev_recv = torch.zeros(self.world * self.n, dtype=torch.int32, device=self.device)
 
+    def _wait_host_send_free(self):
+        # the previous step's asynchronous copy out of the pinned buffer must have finished before it is rewritten
+        if self._copy_done is not None:
+            self._copy_done.synchronize()
+            self._copy_done = None
+
     def gather(self, buf: np.ndarray, n: int, frame_offset: int, root_only: bool = False):
-        if int(n) > self.cap:
-            raise RuntimeError(f"{n} candidates exceed the gather capacity {self.cap}")
-        m, stride = int(n), self.stride
-        hs = self.host_send.numpy()
-        hs[0] = m
-        if m:
-            rec = hs[1:1 + m * stride].reshape(m, stride)
-            rec[:] = buf[: m * stride].reshape(m, stride)
-            rec[:, 0] += frame_offset
+        n, stride = int(n), self.stride
+        while True:
+            self._wait_host_send_free()
+            m = min(n, self.cap)
+            hs = self.host_send.numpy()
+            hs[0] = n                                     # the TRUE count, also when it does not fit
+            if m:
+                rec = hs[1:1 + m * stride].reshape(m, stride)
+                rec[:] = buf[: m * stride].reshape(m, stride)
+                rec[:, 0] += frame_offset
+            if self.world == 1:
+                counts = np.array([n])
+            else:
+                # only the used prefix crosses PCIe; the collective moves the fixed-size payload
+                self.dev_send[: 1 + m * stride].copy_(self.host_send[: 1 + m * stride], non_blocking=True)
+                if self.device.type == "cuda":
+                    self._copy_done = self.torch.cuda.Event()
+                    self._copy_done.record(self.torch.cuda.current_stream(self.device))
+                self.dist.all_gather_into_tensor(self.dev_recv, self.dev_send)
+                self.collectives += 1
+                counts = self.dev_recv[:: self.n].cpu().numpy()      # world ints, read by EVERY rank
+            need = int(counts.max())
+            if need <= self.cap:
+                break
+            self._wait_host_send_free()
+            self._alloc(_grown(need))                     # same decision on every rank; repeat the collective
+            self.grown += 1
         if self.world == 1:
-            return hs[1:1 + m * stride].reshape(m, stride).copy()
-        # only the used prefix crosses PCIe; the collective moves the fixed-size payload
-        self.dev_send[: 1 + m * stride].copy_(self.host_send[: 1 + m * stride], non_blocking=True)
-        self.dist.all_gather_into_tensor(self.dev_recv, self.dev_send)
+            return hs[1:1 + n * stride].reshape(n, stride).copy()
         if root_only and self.rank != 0:
             return None
-        counts = self.dev_recv[:: self.n].cpu().numpy()          # world ints
         parts = []
         for r in range(self.world):
             k = int(counts[r]) * stride
@@ -93,15 +144,6 @@ class CandidateGatherer:
 
 
 def gather_candidates(buf: np.ndarray, n: int, stride: int, cap: int, frame_offset: int, device) -> np.ndarray:
-    """One all_gather of the candidate payloads; every rank returns the concatenated (N, stride) records."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    payload = pack_candidates(buf, n, stride, cap, frame_offset)
-    if world == 1:
-        return unpack_gathered([payload], stride)
-    send = torch.from_numpy(payload).to(device)
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send)
-    return unpack_gathered([r.cpu().numpy() for r in recv], stride)
+    """One-shot form: every rank returns the concatenated (N, stride) records.  `cap` is only the initial
+    capacity (see CandidateGatherer)."""
+    return CandidateGatherer(stride, cap, device).gather(buf, n, frame_offset)

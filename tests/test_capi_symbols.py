@@ -106,3 +106,15 @@ def test_conv_tile_cover_is_complete_and_minimal():
             for tw, th in shapes:
                 best[w] = min(best[w], best[max(w - tw, 0)] + tw * math.ceil(rows / th) * th)
         assert lanes == best[cols], (rows, cols, lanes, best[cols])
+
+
+def test_no_exception_crosses_the_abi(lib):
+    """include/pbd.h: "No exception crosses this ABI".  Every extern "C" body runs inside the same guard; its
+    self-test entry point throws inside that guard (bad_alloc, a length_error from an absurd std::vector size,
+    another std::exception) and must come back with a status code instead of std::terminate."""
+    assert lib.pbd_debug_guard_selftest(0) == -6          # PBD_ERR_NOMEM
+    assert b"memory" in lib.pbd_last_error(None)
+    assert lib.pbd_debug_guard_selftest(1) == -6
+    assert lib.pbd_debug_guard_selftest(2) == -1          # PBD_ERR_INVALID
+    assert b"selftest" in lib.pbd_last_error(None)
+    assert lib.pbd_debug_guard_selftest(3) == 0

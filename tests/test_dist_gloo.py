@@ -23,7 +23,7 @@ def test_shard_range_covers_all_frames():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_pack_unpack_roundtrip_and_truncation():
+def test_pack_unpack_roundtrip_and_overflow():
     stride = 8 + 4 * 3
     rng = np.random.default_rng(0)
     buf = rng.integers(0, 1000, 5 * stride).astype(np.int32)
@@ -33,7 +33,10 @@ def test_pack_unpack_roundtrip_and_truncation():
     assert rec.shape == (5, stride)
     assert np.array_equal(rec[:, 1:], buf.reshape(5, stride)[:, 1:])
     assert np.array_equal(rec[:, 0], buf.reshape(5, stride)[:, 0] + 10)
-    assert pd.pack_candidates(buf, 5, stride, cap=3)[0] == 3       # capacity clamps
+    short = pd.pack_candidates(buf, 5, stride, cap=3)               # does not fit: the true count stays visible ...
+    assert short[0] == 5
+    with pytest.raises(OverflowError):                              # ... and unpacking refuses instead of truncating
+        pd.unpack_gathered([short], stride)
     assert pd.unpack_gathered([pd.pack_candidates(buf, 0, stride, cap=4)], stride).shape == (0, stride)
 
 
@@ -132,3 +135,59 @@ def test_candidate_gatherer_world2():
             assert res[1][step] is None
         else:
             assert np.array_equal(res[1][step], want)
+
+
+def _overflow_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from partsbaseddetector_amd import dist as pd
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        stride = 8 + 4 * 26                            # the person model's record
+        g = pd.CandidateGatherer(stride, cap=8192, device="cpu")
+        log = []
+        # step 0: both fit; step 1: rank 1 holds 30 000 records (the 8 x 1080p batch of round 1 produced 25 635) while
+        # rank 0 holds 5; step 2: back to small counts on the grown buffers; step 3: rank 0 empty
+        for step, counts in enumerate([(40, 50), (5, 30000), (7, 3), (0, 9)]):
+            n = counts[rank]
+            buf = np.zeros(n * stride, np.int32)
+            r = buf.reshape(n, stride)
+            r[:, 0] = np.arange(n) % 8
+            r[:, 1] = rank
+            r[:, 2] = step
+            r[:, 3] = np.arange(n)
+            before = g.collectives
+            rec = g.gather(buf, n, frame_offset=8 * rank, root_only=True)
+            log.append((g.collectives - before, g.cap, None if rec is None else rec[:, :4].copy()))
+        q.put((rank, log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gatherer_overflow_grows_instead_of_raising():
+    """A rank with more candidates than the gather capacity must not raise before the collective (the other ranks
+    would block inside it): every rank enters, all see the true counts, all grow, and the collective is repeated."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(2):
+        ncoll = [e[0] for e in res[rank]]
+        caps = [e[1] for e in res[rank]]
+        assert ncoll == [1, 2, 1, 1], ncoll           # one collective per step; the overflow step repeats it once
+        assert caps[0] == 8192 and caps[1] >= 30000 and caps[1] == caps[2] == caps[3]
+        assert all(e[2] is None for e in res[1])       # root_only
+    for step, counts in enumerate([(40, 50), (5, 30000), (7, 3), (0, 9)]):
+        rec = res[0][step][2]
+        assert rec.shape[0] == sum(counts)
+        want_rank = np.concatenate([np.full(c, r) for r, c in enumerate(counts)])
+        assert np.array_equal(rec[:, 1], want_rank) and np.all(rec[:, 2] == step)
+        want_idx = np.concatenate([np.arange(c) for c in counts])
+        assert np.array_equal(rec[:, 3], want_idx)
+        assert np.array_equal(rec[:, 0], want_idx % 8 + 8 * want_rank)      # frame ids made global

@@ -226,6 +226,50 @@ def test_errors(det_mod):
     det.hd.close()
 
 
+def test_allocation_failure_is_a_status_code(det_mod):
+    """An allocation that cannot succeed (a candidate buffer of ~1 TB) comes back as PBD_ERR_NOMEM with a message,
+    and the handle stays usable -- the reference reports errors as CV_Error / bool, never by dying
+    (src/HOGFeatures.cpp:141-145, src/FileStorageModel.cpp:100-101)."""
+    from partsbaseddetector_amd._lib import PbdError
+    model = M.synthetic_tiny_model(thresh=0.5)
+    im = synth.synthetic_frame(1, 100, 100)
+    hd = det_mod.Handle(model, device=0, max_candidates=2 ** 31 - 1)
+    buf = np.zeros(16 * hd.stride, np.int32)
+    import ctypes as C
+    n = C.c_int()
+    rc = hd.lib.pbd_detect(hd.h, im.ctypes.data, 100, 100, 3, im.strides[0], buf.ctypes.data, 16, C.byref(n))
+    assert rc == -6, (rc, hd.lib.pbd_last_error(hd.h))
+    assert b"hipMalloc" in hd.lib.pbd_last_error(hd.h) or b"memory" in hd.lib.pbd_last_error(hd.h)
+    hd.close()
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    assert len(det.detect(im)) > 0
+    det.hd.close()
+
+
+def test_set_filters_that_do_not_cover_the_model(det_mod, oracle):
+    """setFilters() with fewer filters than the model's filter ids: the convolution engine keeps working on its own,
+    the model-dependent calls refuse (PBD_ERR_STATE) instead of indexing response planes out of bounds; installing a
+    covering bank again restores them, with the part boxes following the new filter size."""
+    from partsbaseddetector_amd._lib import PbdError
+    model = M.synthetic_tiny_model(thresh=0.5)
+    flat = model.flatten()
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    im = synth.synthetic_frame(1, 100, 100)
+    rng = np.random.default_rng(1)
+    det.convolution_engine_.setFilters([rng.standard_normal((5, 160)).astype(np.float32) for _ in range(flat.nfilters - 1)])
+    feat = rng.random((9, 11 * 32), dtype=np.float32)
+    assert det.convolution_engine_.pdf([feat])[0].shape == (flat.nfilters - 1, 9, 11)
+    with pytest.raises(PbdError) as e:
+        det.detect(im)
+    assert e.value.code == -5
+    filters = [flat.filters_f32[int(flat.filter_offset[f]):int(flat.filter_offset[f]) + 5 * 160].reshape(5, 160) for f in range(flat.nfilters)]
+    det.convolution_engine_.setFilters(filters)
+    _compare_candidates(det.detect(im), oracle.detect(flat, im))
+    det.hd.close()
+
+
 @pytest.mark.parametrize("shape,seed", [((480, 640), 1), ((1080, 1920), 2)])
 def test_person_model_full_size_frames(det_mod, oracle, shape, seed):
     """BASELINE configs[1]/[3] sizes: one 640x480 and one 1920x1080 frame, whole path, vs the oracle."""
