@@ -227,17 +227,18 @@ def test_errors(det_mod):
 
 
 def test_allocation_failure_is_a_status_code(det_mod):
-    """An allocation that cannot succeed (a candidate buffer of ~1 TB) comes back as PBD_ERR_NOMEM with a message,
+    """An allocation that cannot succeed (a candidate buffer of ~1 TB: 2^31 records of the person model's 448 bytes;
+    the MI355X has 288 GB) comes back as PBD_ERR_NOMEM with a message,
     and the handle stays usable -- the reference reports errors as CV_Error / bool, never by dying
     (src/HOGFeatures.cpp:141-145, src/FileStorageModel.cpp:100-101)."""
     from partsbaseddetector_amd._lib import PbdError
-    model = M.synthetic_tiny_model(thresh=0.5)
-    im = synth.synthetic_frame(1, 100, 100)
+    model = M.synthetic_person_model(thresh=17.9)
+    im = synth.synthetic_frame(1, 120, 160)
     hd = det_mod.Handle(model, device=0, max_candidates=2 ** 31 - 1)
     buf = np.zeros(16 * hd.stride, np.int32)
     import ctypes as C
     n = C.c_int()
-    rc = hd.lib.pbd_detect(hd.h, im.ctypes.data, 100, 100, 3, im.strides[0], buf.ctypes.data, 16, C.byref(n))
+    rc = hd.lib.pbd_detect(hd.h, im.ctypes.data, 120, 160, 3, im.strides[0], buf.ctypes.data, 16, C.byref(n))
     assert rc == -6, (rc, hd.lib.pbd_last_error(hd.h))
     assert b"hipMalloc" in hd.lib.pbd_last_error(hd.h) or b"memory" in hd.lib.pbd_last_error(hd.h)
     hd.close()
