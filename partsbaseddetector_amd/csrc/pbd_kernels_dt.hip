@@ -38,30 +38,70 @@ __device__ __forceinline__ R dt_isect(double a, double b, int x0, int x1, R y0f,
     const double num = ((y1 - y0) - b * (double)(x1 - x0)) + a * (double)(x1 * x1 - x0 * x0);
     return (R)(num / ((2 * a) * (double)(x1 - x0)));
 }
-template <typename R>
+template <typename R, bool BZERO>
 __device__ __forceinline__ R dt_val(double a, double b, int x, R y)
 {   // Quadratic::operator()(x, y), :103-105
+    if (BZERO) return (R)(a * (double)(x * x) + (double)y);     // b == -0.0: t + (-0.0) == t for every t
     return (R)((a * (double)(x * x) + b * (double)x) + (double)y);
 }
+// entries of the 1/d table, padded so that what follows stays 16-byte aligned
+__host__ __device__ inline size_t dt_invd_entries(int pitch) { return (size_t)((pitch + 1) & ~1); }
+
 template <typename R> __device__ __forceinline__ R neg_inf();
 template <> __device__ __forceinline__ float neg_inf<float>() { return -INFINITY; }
 template <> __device__ __forceinline__ double neg_inf<double>() { return -(double)INFINITY; }
 
 constexpr int kBuildCH = 8;     // source elements fetched from LDS ahead of their use
 constexpr int kOutCH = 16;      // outputs leaving together (one 32-byte pointer store per lane in the rows pass)
+constexpr int kRing = 8;        // z of the entries just below the top (power of two)
 
 typedef short v8s_u __attribute__((ext_vector_type(8), aligned(2)));
 
+// The intersection for T = float without the fp64 divide.  The reference value is RN_float(RN_double(num / den)),
+// den = (2a) * d exactly (a is a float widened to double, d < 2^13).  qt = num * (RN(1/(2a)) * RN(1/d)) differs
+// from RN_double(num / den) by at most 6 double ulps (three roundings of 2^-53 in the reciprocal, one in the
+// product, half an ulp in RN_double), so (float)qt is the reference value unless qt lies within 6 ulps of a
+// midpoint between two floats -- bits 0..28 of the double significand within 6 of 2^28 -- or outside the normal
+// float range (where the float grid is different) or not finite.  Those lanes (about one in 2^22) take the divide.
+struct FastIsect {
+    double a, b, inv2a, den2a;
+    const double *invd;           // LDS: invd[d] = RN(1.0 / d)
+};
+template <bool BZERO>
+__device__ __forceinline__ float isect_f32(const FastIsect &f, int x0, int x1, float y0f, float y1f)
+{
+    const int d = x1 - x0;
+    const double dd = (double)d;
+    double num = (double)y1f - (double)y0f;
+    if (!BZERO) num = num - f.b * dd;          // b == -0.0: (y1 - y0) - (-0.0) leaves every value but -0.0 unchanged, and the sum below is never 0
+    num = num + f.a * (double)(d * (x1 + x0)); // x1*x1 - x0*x0 in int, as the reference
+    const double qt = num * (f.inv2a * f.invd[d]);
+    const unsigned lo = (unsigned)__double2loint(qt), hi = (unsigned)__double2hiint(qt);
+    const unsigned dist = (lo & 0x1FFFFFFFu) - (0x10000000u - 8u);          // < 17  <=>  within 8 of the midpoint
+    const unsigned ex = ((hi >> 20) & 0x7FFu) - (1023u - 120u);              // < 241 <=>  2^-120 <= |qt| < 2^121
+    float s = (float)qt;
+    if (__builtin_expect(dist < 17u || ex >= 241u, 0)) s = (float)(num / (f.den2a * dd));
+    return s;
+}
+
 // per-lane envelope state
-template <typename R>
+template <typename R, bool BZERO>
 struct Envelope {
     const R *row;                 // this problem's staged source row (LDS)
     unsigned *mask;               // this lane's column of the [word][64] survivor mask (LDS)
+    R *ring;                      // this lane's column of the [kRing][64] z ring (LDS)
     double a, b;
+    FastIsect fi;
     int vk; R sk, zk;             // top entry
-    int vb; R sb;                 // entry below the top (vb == -1: none)
-    unsigned cw; int cwi;         // survivors strictly below `vb`: cached word and its index; LDS words above cwi are 0
+    int k, lo;                    // index of the top entry in the stack; the ring holds z of the entries [lo, k)
+    int pb; R sb;                 // entry directly below the top when known from the last pop (pb < 0: not known)
+    unsigned cw; int cwi;         // survivors below the top: cached mask word and its index; LDS words above cwi are 0
 
+    __device__ __forceinline__ R isect(int x0, int x1, R y0, R y1) const
+    {
+        if constexpr (sizeof(R) == 4) return isect_f32<BZERO>(fi, x0, x1, y0, y1);
+        else return dt_isect<R>(a, b, x0, x1, y0, y1);
+    }
     __device__ __forceinline__ void add_below(int p)
     {   // p is higher than every member
         const int w = p >> 5;
@@ -73,38 +113,50 @@ struct Envelope {
             cwi = w; cw = bit;
         }
     }
-    __device__ __forceinline__ int take_highest()
-    {   // the set is not empty
+    __device__ __forceinline__ void settle()
+    {   // move the cursor down to the highest non-empty word (the set is not empty)
         while (cw == 0) {
             mask[cwi * 64] = 0;
             --cwi;
             cw = mask[cwi * 64];
         }
-        const int hb = 31 - __clz((int)cw);
-        cw &= ~(1u << hb);
-        return (cwi << 5) + hb;
     }
     __device__ __forceinline__ void pop()
-    {   // requires vk != 0, i.e. an entry below exists
-        vk = vb; sk = sb;
-        if (vb == 0) {
-            zk = neg_inf<R>(); vb = -1;
+    {   // requires vk != 0: the set of survivors below the top is not empty
+        settle();
+        const int hb = 31 - __clz((int)cw);
+        const int pnew = (cwi << 5) + hb;
+        cw &= ~(1u << hb);
+        sk = (pb == pnew) ? sb : row[pnew];
+        vk = pnew;
+        pb = -1;
+        --k;
+        if (pnew == 0) {
+            zk = neg_inf<R>();
+        } else if (k >= lo) {
+            zk = ring[(k & (kRing - 1)) * 64];
         } else {
-            const int pp = take_highest();
-            const R sp = row[pp];
-            zk = dt_isect<R>(a, b, pp, vk, sp, sk);   // as computed when entry vk was pushed onto entry pp
-            vb = pp; sb = sp;
+            // z of the new top = its intersection with the entry below it, as computed when it was pushed
+            settle();
+            const int p2 = (cwi << 5) + 31 - __clz((int)cw);
+            const R s2 = row[p2];
+            zk = isect(p2, vk, s2, sk);
+            pb = p2; sb = s2;
+            lo = k;
         }
     }
     __device__ __forceinline__ void step(int q, R sq)
     {   // include/DistanceTransform.hpp:158-169
-        R s = dt_isect<R>(a, b, vk, q, sk, sq);
+        R s = isect(vk, q, sk, sq);
         while (s <= zk && vk != 0) {
             pop();
-            s = dt_isect<R>(a, b, vk, q, sk, sq);
+            s = isect(vk, q, sk, sq);
         }
-        if (vb >= 0) add_below(vb);
-        vb = vk; sb = sk;
+        add_below(vk);
+        ring[(k & (kRing - 1)) * 64] = zk;
+        ++k;
+        if (k - lo > kRing) lo = k - kRing;
+        pb = vk; sb = sk;
         vk = q; sk = sq; zk = s;
     }
 };
@@ -113,7 +165,7 @@ struct Envelope {
 
 // ROWS: problem = row y of a score plane, N = W; value out transposed tmp[x][y], pointer out row-major Ix[y][x].
 // !ROWS: problem = column x (contiguous in the transposed tmp), N = H; value out dt[y][x], pointer out IyRaw[y][x].
-template <typename R, bool ROWS>
+template <typename R, bool ROWS, bool BZERO>
 __global__ __launch_bounds__(64) void k_dt_pass(DpParams p, DtPassArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,12 +198,16 @@ __global__ __launch_bounds__(64) void k_dt_pass(DpParams p, DtPassArgs A)
     R *vout = static_cast<R *>(ROWS ? p.tmp : p.dt) + jbase + r;                         // element q at vout[q * L]
     int16_t *pout = ROWS ? p.IxRaw + jbase + (size_t)r * N : p.IyRaw + jbase + r;       // ROWS: pout[q], else pout[q * L]
 
-    // ---- LDS: [rw][pitch] source rows | 64 row pointers | [nw][64] survivor-mask words ----
-    R *srcL = reinterpret_cast<R *>(smem);
-    const R **tab = reinterpret_cast<const R **>(smem + (size_t)A.rw * A.pitch * sizeof(R));
-    unsigned *maskL = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tab) + 64 * sizeof(const R *));
+    // ---- LDS: 1/d table (doubles) | 64 row pointers | [kRing][64] z ring | [nw][64] survivor-mask words | [rw][pitch] source rows
+    double *invd = reinterpret_cast<double *>(smem);
+    const R **tab = reinterpret_cast<const R **>(invd + dt_invd_entries(A.pitch));
+    R *ringL = reinterpret_cast<R *>(tab + 64);
+    unsigned *maskL = reinterpret_cast<unsigned *>(ringL + kRing * 64);
+    R *srcL = reinterpret_cast<R *>(maskL + (size_t)A.nw * 64);
     tab[lane] = src;
     for (int w = 0; w < A.nw; ++w) maskL[w * 64 + lane] = 0;
+    if (sizeof(R) == 4)
+        for (int d = lane; d < N; d += 64) invd[d] = 1.0 / (double)max(d, 1);
     __syncthreads();
     {   // staging: element e of the wave's nact x N block -> (problem e / N, q = e % N); consecutive lanes read consecutive q
         const unsigned magic = N > 1 ? 0xFFFFFFFFu / (unsigned)N + 1u : 0u;   // e / N = umulhi(e, magic) for e * N < 2^32
@@ -176,14 +232,16 @@ __global__ __launch_bounds__(64) void k_dt_pass(DpParams p, DtPassArgs A)
     }
     __syncthreads();
 
-    Envelope<R> env;
+    Envelope<R, BZERO> env;
     env.row = srcL + (size_t)(act ? lane : lane % nact) * A.pitch;
     env.mask = maskL + lane;
+    env.ring = ringL + lane;
     env.a = ROWS ? job.ax : job.ay;
     env.b = ROWS ? job.bx : job.by;
+    env.fi.a = env.a; env.fi.b = env.b; env.fi.den2a = 2 * env.a; env.fi.inv2a = 1.0 / (2 * env.a); env.fi.invd = invd;
     const int os0 = ROWS ? job.osx : job.osy;
     env.vk = 0; env.sk = env.row[0]; env.zk = neg_inf<R>();
-    env.vb = -1; env.sb = (R)0;
+    env.k = 0; env.lo = 0; env.pb = -1; env.sb = (R)0;
     env.cw = 0; env.cwi = 0;
     // ---- build the envelope, q ascending in lockstep ----
     for (int q0 = 1; q0 < N; q0 += kBuildCH) {
@@ -207,7 +265,7 @@ __global__ __launch_bounds__(64) void k_dt_pass(DpParams p, DtPassArgs A)
             if (q < N) {
                 const R osf = (R)(os0 + q);
                 while (!(env.zk < osf)) env.pop();      // z of position 0 is -inf: the walk ends there
-                out[i] = dt_val<R>(env.a, env.b, os0 + q - env.vk, env.sk);
+                out[i] = dt_val<R, BZERO>(env.a, env.b, os0 + q - env.vk, env.sk);
                 ptr[i] = env.vk;
             }
         }
@@ -238,23 +296,36 @@ __global__ __launch_bounds__(64) void k_dt_pass(DpParams p, DtPassArgs A)
     }
 }
 
-template <typename R, bool ROWS>
+template <typename R, bool ROWS, bool BZERO>
 static void launch_one(const DpParams &p, const DtPassArgs &a, size_t lds_bytes, hipStream_t s)
 {
     static bool attr_set = false;       // dynamic LDS above 64 KB has to be allowed once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dt_pass<R, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dt_pass<R, ROWS, BZERO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_dt_pass<R, ROWS>), dim3(a.wbegin[a.n]), dim3(64), lds_bytes, s, p, a);
+    hipLaunchKernelGGL((k_dt_pass<R, ROWS, BZERO>), dim3(a.wbegin[a.n]), dim3(64), lds_bytes, s, p, a);
 }
 
-void launch_dt_pass(const DpParams &p, const DtPassArgs &a, size_t lds_bytes, bool rows, bool f64, hipStream_t s)
+size_t dt_pass_lds_bytes(int n, int rw, size_t rs)
+{
+    return dt_invd_entries(n | 1) * sizeof(double) + 64 * sizeof(void *) + (size_t)kRing * 64 * rs + (size_t)((n + 31) / 32) * 256 +
+           (size_t)rw * (size_t)(n | 1) * rs;
+}
+
+// bzero: the linear deformation term of every job of the group is exactly -0.0 in this pass's direction
+void launch_dt_pass(const DpParams &p, const DtPassArgs &a, size_t lds_bytes, bool rows, bool bzero, bool f64, hipStream_t s)
 {
     if (a.n == 0 || a.wbegin[a.n] == 0) return;
-    if (f64) { if (rows) launch_one<double, true>(p, a, lds_bytes, s); else launch_one<double, false>(p, a, lds_bytes, s); }
-    else { if (rows) launch_one<float, true>(p, a, lds_bytes, s); else launch_one<float, false>(p, a, lds_bytes, s); }
+#define PBD_DT_GO(R, RW)                                                            \
+    do {                                                                            \
+        if (bzero) launch_one<R, RW, true>(p, a, lds_bytes, s);                     \
+        else launch_one<R, RW, false>(p, a, lds_bytes, s);                          \
+    } while (0)
+    if (f64) { if (rows) PBD_DT_GO(double, true); else PBD_DT_GO(double, false); }
+    else { if (rows) PBD_DT_GO(float, true); else PBD_DT_GO(float, false); }
+#undef PBD_DT_GO
 }
 
 }  // namespace pbd
