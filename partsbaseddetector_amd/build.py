@@ -13,7 +13,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpbd_hip.so")
-SOURCES = ["pbd_capi.hip", "pbd_kernels_features.hip", "pbd_kernels_conv.hip", "pbd_kernels_conv_mfma.hip", "pbd_kernels_dp.hip", "pbd_kernels_dt.hip"]
+SOURCES = ["pbd_capi.hip", "pbd_kernels_features.hip", "pbd_kernels_conv.hip", "pbd_kernels_conv_mfma.hip", "pbd_kernels_dp.hip"]
 HEADERS = ["pbd_internal.h", os.path.join("..", "..", "include", "pbd.h")]
 FLAGS = os.environ.get("PBD_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall"]

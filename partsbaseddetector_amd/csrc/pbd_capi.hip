@@ -113,14 +113,14 @@ struct Plan {
     DevTable<ConvTile> d_tiles, d_shaped;
     int nshaped[3] = {0, 0, 0};
     DevTable<int> d_row2level, d_rowoff, d_col2level, d_coloff;
+    DevTable<long long> d_stk_row_off, d_stk_col_off;
+    long long stk_per_jf = 0;
     DevTable<float> d_scales;
-    // distance-transform launch classes (levels of similar row / column length share one dynamic-LDS size)
-    struct DtClass { std::vector<int> levels; int nmax = 0, rw = 64, pitch = 1, nw = 1; size_t lds = 0; };
-    std::vector<DtClass> row_classes, col_classes;
     void release()
     {
         d_lv.release(); d_tabx.release(); d_taby.release(); d_tiles.release(); d_shaped.release();
         d_row2level.release(); d_rowoff.release(); d_col2level.release(); d_coloff.release(); d_scales.release();
+        d_stk_row_off.release(); d_stk_col_off.release();
     }
     ~Plan() { release(); }
 };
@@ -132,7 +132,6 @@ struct Group {   // DT jobs of the parts of one tree depth + combine jobs of the
     DevTable<DtJob> d_jobs;
     DevTable<ChildDesc> d_childs;
     DevTable<CombineJob> d_cjobs;
-    bool bzero_x = false, bzero_y = false;   // every job's linear deformation term is exactly -0.0 (w1 / w3 == +0.0f)
 };
 
 struct Prof {
@@ -210,7 +209,7 @@ struct pbd_handle {
 
     // workspace
     DevBuf frames, pyr, gmag, gori, hist, norm, feat, resp, acc, Ix, Iy, Ik, rootv, rooti;
-    DevBuf tmp, dt, IxRaw, IyRaw, cand, count, scales_tmp;
+    DevBuf tmp, dt, IxT, IxRaw, IyRaw, stk, cand, count, scales_tmp;
     std::vector<int32_t> cand_host;
 
     Prof prof;
@@ -303,41 +302,8 @@ static void cover_level(int l, int rows, int cols, std::vector<ConvTile> *shaped
     }
 }
 
-// Group the levels by the LDS one wave needs for its staged rows (64 x pitch x sizeof(T)), so that the launch of the
-// short levels is not limited to the occupancy the longest level allows.  Budgets = 160 KB / {16, 8, 5, 4, 3, 2, 1}
-// waves per CU; a row too long for 64 problems per wave gets 32, 16 or 8.
-void build_dt_classes(const Plan &P, size_t rs, bool rows, std::vector<Plan::DtClass> &out)
+hipError_t finish_plan_tables(Plan &P)
 {
-    static const size_t budgets[] = {10240, 20480, 32768, 40960, 54272, 81920, 163840};
-    auto need = [&](int n, int rw) { return dt_pass_lds_bytes(n, rw, rs); };
-    std::vector<std::pair<int, int>> order;   // (-length, level): longest first
-    for (int l = 0; l < P.nlevels; ++l) {
-        const int n = rows ? P.lv[l].cols : P.lv[l].rows, cnt = rows ? P.lv[l].rows : P.lv[l].cols;
-        if (n > 0 && cnt > 0) order.push_back({-n, l});
-    }
-    std::sort(order.begin(), order.end());
-    out.clear();
-    int cur_b = -1, cur_rw = 0;
-    for (auto &e : order) {
-        const int n = -e.first, l = e.second;
-        int rw = 64;
-        while (rw > 8 && need(n, rw) > budgets[6]) rw /= 2;
-        int b = 0;
-        while (b < 6 && need(n, rw) > budgets[b]) ++b;
-        if (out.empty() || b != cur_b || rw != cur_rw) {
-            out.push_back(Plan::DtClass{});
-            Plan::DtClass &c = out.back();
-            c.nmax = n; c.rw = rw; c.pitch = n | 1; c.nw = (n + 31) / 32; c.lds = need(n, rw);
-            cur_b = b; cur_rw = rw;
-        }
-        out.back().levels.push_back(l);
-    }
-}
-
-hipError_t finish_plan_tables(Plan &P, size_t rs)
-{
-    build_dt_classes(P, rs, true, P.row_classes);
-    build_dt_classes(P, rs, false, P.col_classes);
     // flat row / column lookup and conv tiles over the feature maps
     std::vector<int> row2level, rowoff(P.nlevels + 1, 0), col2level, coloff(P.nlevels + 1, 0);
     std::vector<ConvTile> tiles, shaped[3];
@@ -361,9 +327,28 @@ hipError_t finish_plan_tables(Plan &P, size_t rs)
     P.nrows_flat = (int)row2level.size();
     P.ncols_flat = (int)col2level.size();
     P.ntiles = (int)tiles.size();
+    // wave-private stack regions: a wave of 64 flat rows (columns) needs 64 x ceil(longest row in the wave / 2)
+    // two-entry records; levels are ordered large to small, but take the maximum to be safe
+    std::vector<long long> srow, scol;
+    long long tot_r = 0, tot_c = 0;
+    for (int w0 = 0; w0 < P.nrows_flat; w0 += 64) {
+        int mx = 0;
+        for (int r = w0; r < std::min(w0 + 64, P.nrows_flat); ++r) mx = std::max(mx, P.lv[row2level[r]].cols);
+        srow.push_back(tot_r);
+        tot_r += 64LL * ((mx + 1) / 2);
+    }
+    for (int w0 = 0; w0 < P.ncols_flat; w0 += 64) {
+        int mx = 0;
+        for (int c = w0; c < std::min(w0 + 64, P.ncols_flat); ++c) mx = std::max(mx, P.lv[col2level[c]].rows);
+        scol.push_back(tot_c);
+        tot_c += 64LL * ((mx + 1) / 2);
+    }
+    P.stk_per_jf = std::max(tot_r, tot_c);
     std::vector<ConvTile> all;
     for (int k = 0; k < 3; ++k) { P.nshaped[k] = (int)shaped[k].size(); all.insert(all.end(), shaped[k].begin(), shaped[k].end()); }
     hipError_t e;
+    if ((e = P.d_stk_row_off.upload(srow)) != hipSuccess) return e;
+    if ((e = P.d_stk_col_off.upload(scol)) != hipSuccess) return e;
     if ((e = P.d_lv.upload(P.lv)) != hipSuccess) return e;
     if ((e = P.d_tiles.upload(tiles)) != hipSuccess) return e;
     if ((e = P.d_shaped.upload(all)) != hipSuccess) return e;
@@ -444,7 +429,7 @@ int get_image_plan(pbd_handle *h, int rows, int cols, Plan **out)
     if (P->npix_resized == 0) P->npix_resized = pix;
     HIPCHK(h, P->d_tabx.upload(tabx));
     HIPCHK(h, P->d_taby.upload(taby));
-    HIPCHK(h, finish_plan_tables(*P, h->rs));
+    HIPCHK(h, finish_plan_tables(*P));
     // HOG coordinate table grows with the largest frame seen
     const int need = std::max(rows, cols) + 4 * h->sbin + 8;
     if (need > h->coord_n) {
@@ -501,7 +486,7 @@ int get_dims_plan(pbd_handle *h, int nlevels, const int *rows, const int *cols, 
         cell += (long long)rows[l] * cols[l];
     }
     P->cell_per_frame = cell;
-    HIPCHK(h, finish_plan_tables(*P, h->rs));
+    HIPCHK(h, finish_plan_tables(*P));
     *out = P.get();
     cache_plan(h, std::move(P));
     return PBD_OK;
@@ -741,11 +726,6 @@ int build_model(pbd_handle *h, const pbd_model *m)
                 g.cjobs.push_back(cj);
             }
         }
-        g.bzero_x = g.bzero_y = true;
-        for (const DtJob &j : g.jobs) {
-            if (!(j.bx == 0.0 && std::signbit(j.bx))) g.bzero_x = false;
-            if (!(j.by == 0.0 && std::signbit(j.by))) g.bzero_y = false;
-        }
         h->JGmax = std::max(h->JGmax, (int)g.jobs.size());
         h->groups.push_back(std::move(g));
     }
@@ -859,12 +839,13 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
 int dp_chunk_frames(pbd_handle *h, Plan &P, int want)
 {
     const size_t per_frame = (size_t)P.cell_per_frame * std::max(h->JGmax, 1);
-    // bytes of scratch per chunk (tmp + dt + two int16 pointer planes per cell-job); PBD_DP_BUDGET_MB lets the tests
+    const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
+    // bytes of scratch per chunk (12 B / cell-job + 16 B / two stack entries); PBD_DP_BUDGET_MB lets the tests
     // force several chunks on a small batch
     const char *env_budget = getenv("PBD_DP_BUDGET_MB");
     const size_t budget = env_budget && atoll(env_budget) > 0 ? (size_t)atoll(env_budget) << 20 : (size_t)8 << 30;
     int chunk = std::max(want, 1);
-    while (chunk > 1 && per_frame * (4 + 2 * h->rs) * chunk > budget) chunk = (chunk + 1) / 2;
+    while (chunk > 1 && (per_frame * (6 + 2 * h->rs) + stk_per_frame * (h->f64 ? kStkPairF64 : kStkPairF32)) * chunk > budget) chunk = (chunk + 1) / 2;
     return chunk;
 }
 
@@ -879,10 +860,13 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     HIPCHK(h, h->rootv.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * h->rs, 16)));
     HIPCHK(h, h->rooti.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(int), 16)));
     const size_t per_frame = cpf * std::max(h->JGmax, 1);
+    const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
     HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
+    HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
+    HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkPairF64 : kStkPairF32), 16)));
     return PBD_OK;
 }
 
@@ -895,49 +879,19 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     dp.resp = h->resp.p; dp.acc = h->acc.p;
     dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;
-    dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
+    dp.IxT = h->IxT.as<int16_t>(); dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
+    dp.stk = h->stk.p; dp.stk_per_jf = P.stk_per_jf;
+    dp.stk_row_off = P.d_stk_row_off.d; dp.stk_col_off = P.d_stk_col_off.d;
     dp.biasw = h->d_biasw.d;
     dp.row2level = P.d_row2level.d; dp.rowoff = P.d_rowoff.d; dp.col2level = P.d_col2level.d; dp.coloff = P.d_coloff.d;
     dp.nrows_flat = P.nrows_flat; dp.ncols_flat = P.ncols_flat;
     dp.rootv = h->rootv.p; dp.rooti = h->rooti.as<int>(); dp.rjobs = h->d_rjobs.d;
     dp.frame0 = f0;
-    // The streaming passes (pbd_kernels_dp.hip) handle rows / columns shorter than 512 at high occupancy; longer ones
-    // (feature maps of frames beyond ~2000 pixels) go through the LDS-resident passes of pbd_kernels_dt.hip, which take
-    // any length.  PBD_DT_ONCHIP=1 forces the latter (A/B timing: slower at VGA / HD sizes);
-    // PBD_DT_DIVIDE=1 makes the streaming passes use the fp64 divide instead of the divide-free intersection.
-    static const bool force_onchip = getenv("PBD_DT_ONCHIP") && atoi(getenv("PBD_DT_ONCHIP")) != 0;
-    static const bool force_divide = getenv("PBD_DT_DIVIDE") && atoi(getenv("PBD_DT_DIVIDE")) != 0;
-    int longest = 0;
-    for (const LevelDesc &d : P.lv) longest = std::max(longest, std::max(d.rows, d.cols));
-    const bool legacy = !force_onchip && longest < 512;
-    const bool wide = longest >= 256, nodiv = !force_divide;
-    bool g_bzero_x = false, g_bzero_y = false;
-    auto run_pass = [&](const std::vector<Plan::DtClass> &classes, bool rows) {
-        for (const Plan::DtClass &c : classes) {
-            DtPassArgs a{};
-            a.n = (int)c.levels.size(); a.rw = c.rw; a.pitch = c.pitch; a.nw = c.nw; a.nplanes = dp.JG * nb;
-            long long w = 0;
-            for (int i = 0; i < a.n; ++i) {
-                const LevelDesc &d = P.lv[c.levels[i]];
-                a.level[i] = c.levels[i];
-                a.wbegin[i] = (int)w;
-                w += ((long long)a.nplanes * (rows ? d.rows : d.cols) + c.rw - 1) / c.rw;
-            }
-            a.wbegin[a.n] = (int)w;
-            launch_dt_pass(dp, a, c.lds, rows, rows ? g_bzero_x : g_bzero_y, h->f64, st);
-        }
-    };
     for (auto &g : h->groups) {
         dp.JG = (int)g.jobs.size();
         dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d; dp.childs = g.d_childs.d;
-        g_bzero_x = g.bzero_x; g_bzero_y = g.bzero_y;
-        if (legacy) {
-            { ProfScope ps(h, PBD_K_DT_ROWS, st); launch_dt_rows(dp, nb, h->f64, g.bzero_x, nodiv, wide, st); }
-            { ProfScope ps(h, PBD_K_DT_COLS, st); launch_dt_cols(dp, nb, h->f64, g.bzero_y, nodiv, wide, st); }
-        } else if (dp.JG > 0) {
-            { ProfScope ps(h, PBD_K_DT_ROWS, st); run_pass(P.row_classes, true); }
-            { ProfScope ps(h, PBD_K_DT_COLS, st); run_pass(P.col_classes, false); }
-        }
+        { ProfScope ps(h, PBD_K_DT_ROWS, st); launch_dt_rows(dp, nb, h->f64, st); }
+        { ProfScope ps(h, PBD_K_DT_COLS, st); launch_dt_cols(dp, nb, h->f64, st); }
         { ProfScope ps(h, PBD_K_DP_COMBINE, st); launch_dp_combine(dp, (int)g.cjobs.size(), nb, h->f64, st); }
     }
     { ProfScope ps(h, PBD_K_DP_ROOT, st); launch_dp_root(dp, nb, h->f64, st); }
@@ -1190,7 +1144,7 @@ void pbd_destroy(pbd_handle *h)
     for (auto e : h->chunk_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (DevBuf *b : {&h->frames, &h->pyr, &h->gmag, &h->gori, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
-                      &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->cand, &h->count,
+                      &h->rooti, &h->tmp, &h->dt, &h->IxT, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();
     h->d_wts.release(); h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_walk_off.release();

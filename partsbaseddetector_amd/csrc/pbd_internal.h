@@ -79,6 +79,8 @@ struct PartWalk {             // argmin tree walk, one per part of a component
 };
 
 constexpr int kMaxMix = 8;
+// bytes of one spilled PAIR of envelope-stack entries {T sa, sb, za; unsigned vv;} (natural alignment of T)
+constexpr size_t kStkPairF32 = 16, kStkPairF64 = 32;
 constexpr int kConvTW = 32, kConvTH = 8, kConvQ = 8;
 
 // ---- launch parameter blocks ---------------------------------------------------------------
@@ -139,7 +141,12 @@ struct DpParams {
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
     long long quad_per_frame;
     int max_mix;                  // largest number of mixtures of any part of the model (<= kMaxMix)
-    int16_t *IxRaw, *IyRaw;       // row-major pointers: Ix from the rows pass, IyRaw from the columns pass
+    int16_t *IxT;                 // rows-pass pointers, transposed [x][y]
+    int16_t *IxRaw, *IyRaw;       // row-major pointers written by the columns pass
+    void *stk;                    // [chunk][JG][stk_per_jf] records of two entries, wave-private, lane-interleaved
+    long long stk_per_jf;         // records per (job, frame)
+    const long long *stk_row_off; // per rows-pass wave (64 flat rows): first entry
+    const long long *stk_col_off; // per columns-pass wave
     const DtJob *jobs;
     const ChildDesc *childs;
     const CombineJob *cjobs;
@@ -149,18 +156,6 @@ struct DpParams {
     int nrows_flat, ncols_flat;
     void *rootv; int *rooti;      // R / int [frames][cell_per_frame*NC]
     const RootJob *rjobs;
-};
-
-// One launch of a distance-transform pass covers the levels of one LDS class (rows of similar length).  Passed by
-// value: a wave finds its level with a binary search over wbegin[] in the kernel-argument segment (scalar loads).
-struct DtPassArgs {
-    int n;                          // levels in this class
-    int rw;                         // problems (lanes in use) per wave
-    int pitch;                      // LDS row pitch in elements (odd, >= the longest row of the class)
-    int nw;                         // survivor-mask words per problem = ceil(longest row / 32)
-    int nplanes;                    // (part-mixture jobs of the group) x (frames of the chunk)
-    int level[PBD_MAX_LEVELS];      // longest rows first
-    int wbegin[PBD_MAX_LEVELS + 1]; // first wave of level[i]; wbegin[n] = grid size
 };
 
 struct ArgminParams {
@@ -191,13 +186,8 @@ int conv_occupancy(int nw);
 // PBD_CONV_MFMA_F16: 80 B fp16 records, one MFMA per product tile
 void launch_conv_mfma(const ConvParams &p, const void *wrec, bool f16, int nframes, hipStream_t s);
 constexpr int kMfmaFilterBlock = 160, kMfmaRecBytes = 144, kMfmaRecBytesF16 = 80;
-// on-chip passes (pbd_kernels_dt.hip): rows pass writes tmp (transposed) + IxRaw, columns pass writes dt + IyRaw
-void launch_dt_pass(const DpParams &p, const DtPassArgs &a, size_t lds_bytes, bool rows, bool bzero, bool f64, hipStream_t s);
-size_t dt_pass_lds_bytes(int longest, int problems_per_wave, size_t real_size);   // dynamic LDS of one wave
-// streaming passes (pbd_kernels_dp.hip): high occupancy, rows / columns shorter than 512
-// nodiv: divide-free float intersection; wide: rows / columns of 256..511 elements (shorter otherwise)
-void launch_dt_rows(const DpParams &p, int nframes, bool f64, bool bzero, bool nodiv, bool wide, hipStream_t s);
-void launch_dt_cols(const DpParams &p, int nframes, bool f64, bool bzero, bool nodiv, bool wide, hipStream_t s);
+void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s);
+void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s);
 void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hipStream_t s);
 void launch_dp_root(const DpParams &p, int nframes, bool f64, hipStream_t s);
 void launch_argmin_find(const ArgminParams &p, bool f64, hipStream_t s);

@@ -16,47 +16,17 @@
 
 namespace pbd {
 
-// The intersection for T = float without the fp64 divide (TAB > 0: entries of the 1/d table in LDS).
-// The reference value is RN_float(RN_double(num / den)), den = (2a) * d exactly (a is a float widened to double,
-// d < TAB <= 512).  qt = num * (RN(1/(2a)) * RN(1/d)) differs from RN_double(num / den) by at most 5 double ulps
-// (three roundings of 2^-53 in the reciprocal, one in the product, half an ulp in RN_double), so (float)qt is the
-// reference value unless qt lies within 8 ulps of a midpoint between two floats -- bits 0..28 of the double
-// significand within 8 of 2^28 -- or (float)qt is not a normal float (zero, subnormal, infinite, NaN: the float grid
-// is different there, or the operands were not finite).  Those lanes (about one in 2^24) take the divide.
-// BZERO: the linear coefficient b is exactly -0.0 (deformation weight +0.0f, the usual case): (y1 - y0) - b*d and
-// a*x*x + b*x then equal their first terms for every value that can reach the result (x - (-0.0) = x except for
-// x = -0.0, and the a-term added next is never zero in the intersection; t + (-0.0) = t for every t in the value).
-struct IsectCtx {
-    double a, b, inv2a, den2a;
-    const double *invd;           // LDS: invd[d] = RN(1.0 / d)
-};
-template <typename R, bool BZERO, int TAB>
-__device__ __forceinline__ R ctx_isect(const IsectCtx &c, int x0, int x1, R y0f, R y1f)
-{
-    if constexpr (sizeof(R) == 4 && TAB > 0) {
-        const int d = x1 - x0;
-        const double dd = (double)d;
-        double num = (double)y1f - (double)y0f;
-        if (!BZERO) num = num - c.b * dd;
-        num = num + c.a * (double)(d * (x1 + x0));      // x1*x1 - x0*x0 in int, as the reference
-        const double qt = num * (c.inv2a * c.invd[d]);
-        const unsigned lo = (unsigned)__double2loint(qt);
-        float s = (float)qt;
-        const bool near_mid = ((lo & 0x1FFFFFFFu) - (0x10000000u - 8u)) < 17u;
-        const bool odd_class = !__builtin_isnormal(s);
-        if (__builtin_expect(near_mid || odd_class, 0)) s = (float)(num / (c.den2a * dd));
-        return s;
-    } else {
-        const double y0 = (double)y0f, y1 = (double)y1f;
-        const double num = ((y1 - y0) - c.b * (double)(x1 - x0)) + c.a * (double)(x1 * x1 - x0 * x0);
-        return (R)(num / ((2 * c.a) * (double)(x1 - x0)));
-    }
+template <typename R>
+__device__ __forceinline__ R quad_isect(double a, double b, int x0, int x1, R y0f, R y1f)
+{   // Quadratic::operator()(x0, x1, y0, y1), include/DistanceTransform.hpp:98-100, rounded to T
+    const double y0 = (double)y0f, y1 = (double)y1f;
+    const double num = ((y1 - y0) - b * (double)(x1 - x0)) + a * (double)(x1 * x1 - x0 * x0);
+    return (R)(num / ((2 * a) * (double)(x1 - x0)));
 }
-template <typename R, bool BZERO>
-__device__ __forceinline__ R ctx_val(const IsectCtx &c, int x, R y)
+template <typename R>
+__device__ __forceinline__ R quad_val(double a, double b, int x, R y)
 {   // Quadratic::operator()(x, y), :103-105
-    if (BZERO) return (R)(c.a * (double)(x * x) + (double)y);
-    return (R)((c.a * (double)(x * x) + c.b * (double)x) + (double)y);
+    return (R)((a * (double)(x * x) + b * (double)x) + (double)y);
 }
 template <typename R> struct RealLimits;
 template <> struct RealLimits<float> { static __device__ __forceinline__ float inf() { return INFINITY; } };
@@ -68,146 +38,97 @@ template <> struct RealLimits<double> { static __device__ __forceinline__ double
 //   * the T entries below it live in a per-lane LDS ring (slot = index % T, arrays [T][64] so that a
 //     lane always hits bank lane % 32: conflict-free whatever the lanes' indices are); a pop is three
 //     ds_read_b32, a push three ds_write_b32;
-//   * entries that fall out of the ring are NOT stored anywhere (round 1 spilled them to a global stack: two thirds
-//     of the passes' HBM traffic).  The stack is ordered by position, so all that has to be remembered is WHICH
-//     positions they are: one bit per position in LDS ([word][64], the top non-empty word cached in a register).
-//     When a pop reaches below the ring, the entry comes back as: position = highest set bit; src = re-read from the
-//     lane's own source row (a 16-byte chunk of four consecutive positions is kept, survivors are mostly
-//     adjacent); z = its intersection with the next survivor below, recomputed with the same expression on the same
-//     operands as when it was pushed (bit-identical);
+//   * when a lane's ring is full its two oldest entries (2p, 2p+1) are spilled TOGETHER, as one 16-byte record
+//     {s[2p], s[2p+1], z[2p], v[2p] | v[2p+1] << 16}, to the wave-private, lane-interleaved global stack
+//     ([p][lane]); z[2p+1] is the intersection of the two, recomputed on reload with the same expression on the
+//     same operands (bit-identical).  With small deformation weights almost every parabola stays on the
+//     envelope, so nearly every entry makes this round trip, and since the lanes of a wave spill at different
+//     depths every lane's access is its own memory request: the passes are bound by the NUMBER of requests
+//     (a 6-byte s/v split over two stores was slower, doubling the fp64 divisions costs 3 %), which pairing halves;
 //   * the read-out walks q downwards and POPS: since z[1..ktop] is strictly increasing,
 //     "k = 0; while (z[k+1] < os) k++" (DistanceTransform.hpp:172-178, q ascending) selects the same
 //     k(q) = max{k : z[k] < os(q)} as "k = ktop; while (!(z[k] < os)) k--" with q descending;
 //   * source values are prefetched one chunk ahead and results leave in whole chunks.
 // The arithmetic per element is exactly computeRow's (DistanceTransform.hpp:152-182).
 // ------------------------------------------------------------------------------------------------
+template <typename R> struct StkPairT { R sa, sb, za; unsigned vv; };
+static_assert(sizeof(StkPairT<float>) == kStkPairF32 && sizeof(StkPairT<double>) == kStkPairF64, "host sizes the spill stack with these");
+
 #ifndef PBD_DT_CH
 #define PBD_DT_CH 16
 #endif
-constexpr int kDtCH = PBD_DT_CH;   // elements per streamed chunk (multiple of 8)
-constexpr int kDtWaves = 1;        // waves per workgroup of the DT passes (each wave = 64 rows / columns)
+constexpr int kDtCH = PBD_DT_CH;   // elements per streamed chunk (multiple of 4)
+#ifndef PBD_DT_WAVES
+#define PBD_DT_WAVES 1
+#endif
+constexpr int kDtWaves = PBD_DT_WAVES;   // waves per workgroup of the DT passes (each wave = 64 rows / columns)
 #ifndef PBD_DT_RING
 #define PBD_DT_RING 8
 #endif
 constexpr int kDtT = PBD_DT_RING;    // ring entries per lane (power of two)
 
-typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
-typedef short v8s_u __attribute__((ext_vector_type(8), aligned(2)));
-
 // LDS layout of a wave's ring: [slot][z: 64 x R | s: 64 x R | v: 64 x int]; one address per lane, the rest
-// are immediate offsets.  NW = words of the position mask (rows / columns shorter than 32 * NW).
-// The mask has one bit per position that is on the stack (the top included); its word holding the top is cached in
-// a register, so a push or a pop inside that word touches no memory.  LDS words below the cached one are exact, the
-// ones above it are dead (rewritten before they are read again).
-template <typename R, bool BZERO, int TAB, int NW>
+// are immediate offsets.
+template <typename R>
 struct DtRing {
     static constexpr int kSlotBytes = 64 * (2 * (int)sizeof(R) + 4);
-    static constexpr int kLdsBytes = kDtT * kSlotBytes + NW * 256;
-    static constexpr int kChunk = 16 / (int)sizeof(R);      // source values per re-read chunk
     char *zs;                     // this lane's z of slot 0 (s is 64 R further)
     char *vp;                     // this lane's v of slot 0
-    unsigned *mask;               // this lane's column of the [NW][64] position mask
-    const R *src;                 // this lane's source row / column in global memory (contiguous)
-    IsectCtx c;                   // the job's quadratic
-    int lo;                       // ring holds z, s, v of the stack indices [lo, top)
-    unsigned cw; int cwi;         // cached mask word and its index = (position of the top) >> 5
-    R ch[kChunk]; int cb;         // src[cb .. cb + kChunk), cb a multiple of kChunk (-1: nothing cached)
+    StkPairT<R> *g;               // this lane's column of the global [pair][lane] stack
+    double a, b;                  // the job's quadratic (z of the upper entry of a reloaded pair)
+    int lo;                       // ring holds indices [lo, top); lo is even; entries below lo are spilled
     __device__ __forceinline__ R &z(int slot) { return *reinterpret_cast<R *>(zs + slot * kSlotBytes); }
     __device__ __forceinline__ R &s(int slot) { return *reinterpret_cast<R *>(zs + slot * kSlotBytes + 64 * (int)sizeof(R)); }
     __device__ __forceinline__ int &v(int slot) { return *reinterpret_cast<int *>(vp + slot * kSlotBytes); }
-    __device__ __forceinline__ void push_below(int idx, R zk, R sk, int vk, int q)
-    {   // entry `idx` (the old top, position vk) moves under a new top at position q
+    __device__ __forceinline__ void push_below(int idx, R zk, R sk, int vk)
+    {   // entry `idx` (the old top) moves under a new top
         const int slot = idx & (kDtT - 1);
-        if (idx - lo >= kDtT) lo += 1;          // the ring's oldest entry is overwritten: from now on it lives in the mask only
+        if (idx - lo >= kDtT) {   // ring full: spill its two oldest entries lo, lo + 1 as one record
+            const int sl = lo & (kDtT - 1);
+            g[(size_t)(lo >> 1) * 64] = StkPairT<R>{s(sl), s(sl + 1), z(sl), (unsigned)v(sl) | ((unsigned)v(sl + 1) << 16)};
+            lo += 2;
+        }
         z(slot) = zk; s(slot) = sk; v(slot) = vk;
-        const int w = q >> 5;
-        if (w != cwi) {
-            mask[cwi * 64] = cw;
-            for (int i = cwi + 1; i < w; ++i) mask[i * 64] = 0;   // words skipped after a deep pop
-            cwi = w; cw = 0;
-        }
-        cw |= 1u << (q & 31);
-    }
-    __device__ __forceinline__ R fetch(int pos)
-    {   // src[pos] through the one-chunk cache (reads up to kChunk - 1 values past the row: inside the buffers' slack)
-        const int base = pos & ~(kChunk - 1);
-        if (base != cb) {
-            cb = base;
-            if constexpr (sizeof(R) == 4) {
-                const v4f_u t = *reinterpret_cast<const v4f_u *>(src + base);
-                ch[0] = t.x; ch[1] = t.y; ch[2] = t.z; ch[3] = t.w;
-            } else {
-                const v2d_u t = *reinterpret_cast<const v2d_u *>(src + base);
-                ch[0] = t.x; ch[1] = t.y;
-            }
-        }
-        R r = ch[0];
-#pragma unroll
-        for (int e = 1; e < kChunk; ++e) r = ((pos & (kChunk - 1)) == e) ? ch[e] : r;
-        return r;
     }
     __device__ __forceinline__ void pop(int idx, R &zk, R &sk, int &vk)
-    {   // the top (position vk) leaves the stack, entry `idx` becomes the top
-        cw &= ~(1u << (vk & 31));
+    {   // entry `idx` becomes the top
         // the ring slot is read unconditionally (always a valid LDS address) so that the common case is
-        // plain LDS reads; only a pop below the ring overrides it
+        // plain LDS reads; only a pop below the ring overrides it from the spill stack
         const int slot = idx & (kDtT - 1);
         zk = z(slot); sk = s(slot); vk = v(slot);
         asm volatile("" : "+v"(zk), "+v"(sk), "+v"(vk));   // keep these as LDS reads (not a flat load of a selected pointer)
         if (idx < lo) {
-            // below the ring: the entry is the highest position left in the mask; its source value is re-read and its
-            // z recomputed as the intersection with the next position below -- as when it was pushed
-            while (cw == 0) { mask[cwi * 64] = 0; --cwi; cw = mask[cwi * 64]; }
-            vk = (cwi << 5) + 31 - __clz((int)cw);
-            sk = fetch(vk);
-            if (vk == 0) {
-                zk = -RealLimits<R>::inf();                  // z[0], DistanceTransform.hpp:157
-            } else {
-                unsigned pw = cw & ~(1u << (vk & 31));
-                int pi = cwi;
-                while (pw == 0) { --pi; pw = mask[pi * 64]; }
-                const int vb = (pi << 5) + 31 - __clz((int)pw);
-                const R sb = fetch(vb);
-                zk = ctx_isect<R, BZERO, TAB>(c, vb, vk, sb, sk);
-            }
-            lo = idx;
-        } else if ((vk >> 5) != cwi) {
-            mask[cwi * 64] = cw;
-            cwi = vk >> 5;
-            cw = mask[cwi * 64];
+            // the ring is empty (idx == lo - 1, odd): reload the pair (lo-2, lo-1); the lower entry goes back
+            // into the ring, the upper one is the new top and gets its z recomputed
+            const StkPairT<R> e = g[(size_t)((lo - 2) >> 1) * 64];
+            const int va = (int)(e.vv & 0xffffu), vb = (int)(e.vv >> 16);
+            const int sl = (lo - 2) & (kDtT - 1);
+            z(sl) = e.za; s(sl) = e.sa; v(sl) = va;
+            sk = e.sb; vk = vb;
+            zk = quad_isect<R>(a, b, va, vb, e.sa, e.sb);   // as computed when entry lo-1 was pushed onto entry lo-2
+            lo -= 2;
         }
     }
-    static __device__ __forceinline__ DtRing make(char *smem, int lane, const R *src, double a, double b, const double *invd)
+    // the ring of wave `w` of the workgroup inside `smem`
+    static __device__ __forceinline__ DtRing make(char *smem, int w, int lane, StkPairT<R> *g, double a, double b)
     {
-        DtRing r;
-        r.zs = smem + lane * (int)sizeof(R);
-        r.vp = smem + 128 * (int)sizeof(R) + lane * 4;
-        r.mask = reinterpret_cast<unsigned *>(smem + kDtT * kSlotBytes) + lane;
-        r.src = src;
-        r.c = IsectCtx{a, b, 1.0 / (2 * a), 2 * a, invd};
-        r.lo = 0; r.cw = 1u; r.cwi = 0; r.cb = -1;       // position 0 is on the stack from the start
-#pragma unroll
-        for (int e = 0; e < kChunk; ++e) r.ch[e] = (R)0;
-        return r;
-    }
-    // invd[d] = RN(1.0 / d) for d < TAB, filled by the workgroup (followed by a barrier in the kernel)
-    static __device__ __forceinline__ void fill_invd(double *invd)
-    {
-        if constexpr (sizeof(R) == 4 && TAB > 0)
-            for (int d = threadIdx.x; d < TAB; d += blockDim.x) invd[d] = 1.0 / (double)max(d, 1);
+        char *base = smem + (size_t)w * kDtT * kSlotBytes;
+        return DtRing{base + lane * (int)sizeof(R), base + 128 * (int)sizeof(R) + lane * 4, g, a, b, 0};
     }
 };
 
-template <typename R, class Ring, bool BZERO, int TAB, class LoadChunk, class StoreChunk>
-__device__ __forceinline__ void dt_stream(int N, int os0, Ring ring, LoadChunk load, StoreChunk store)
+// AUX: the read-out additionally streams an int chunk per output chunk (prefetched one chunk ahead, q
+// descending) and hands it to `store` -- the columns pass uses it to carry the rows pass's pointers along.
+template <typename R, bool AUX, class LoadChunk, class StoreChunk, class AuxChunk>
+__device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store,
+                                          AuxChunk aux)
 {
-    const IsectCtx c = ring.c;
     constexpr int CH = kDtCH;
     R cur[CH], nxt[CH];
     load(0, cur);
     int k = 0, vk = 0;
     R zk = -RealLimits<R>::inf(), sk = cur[0];
+    ring.lo = 0;
     for (int q0 = 0; q0 < N; q0 += CH) {
         if (q0 + CH < N) load(q0 + CH, nxt);
 #pragma unroll
@@ -215,13 +136,13 @@ __device__ __forceinline__ void dt_stream(int N, int os0, Ring ring, LoadChunk l
             const int q = q0 + i;
             if (q >= 1 && q < N) {
                 const R sq = cur[i];
-                R s = ctx_isect<R, BZERO, TAB>(c, vk, q, sk, sq);
+                R s = quad_isect<R>(a, b, vk, q, sk, sq);
                 while (s <= zk && k > 0) {
                     --k;
                     ring.pop(k, zk, sk, vk);
-                    s = ctx_isect<R, BZERO, TAB>(c, vk, q, sk, sq);
+                    s = quad_isect<R>(a, b, vk, q, sk, sq);
                 }
-                ring.push_below(k, zk, sk, vk, q);
+                ring.push_below(k, zk, sk, vk);
                 ++k;
                 vk = q; zk = s; sk = sq;
             }
@@ -231,8 +152,13 @@ __device__ __forceinline__ void dt_stream(int N, int os0, Ring ring, LoadChunk l
     }
     // read-out, q descending
     const int nch = (N + CH - 1) / CH;
+    int aux_cur[CH], aux_nxt[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { aux_cur[i] = 0; aux_nxt[i] = 0; }
+    if (AUX) aux((nch - 1) * CH, aux_cur);
     for (int cidx = nch - 1; cidx >= 0; --cidx) {
         const int q0 = cidx * CH;
+        if (AUX && cidx > 0) aux(q0 - CH, aux_nxt);
         R out[CH];
         int ptr[CH];
 #pragma unroll
@@ -245,47 +171,30 @@ __device__ __forceinline__ void dt_stream(int N, int os0, Ring ring, LoadChunk l
                     --k;
                     ring.pop(k, zk, sk, vk);
                 }
-                out[i] = ctx_val<R, BZERO>(c, os0 + q - vk, sk);
+                out[i] = quad_val<R>(a, b, os0 + q - vk, sk);
                 ptr[i] = vk;
             }
         }
-        store(q0, out, ptr);
-    }
-}
-
-static_assert(kDtCH % 8 == 0, "the rows pass stores its int16 pointers 8 at a time");
-
-template <typename R>
-__device__ __forceinline__ void load_chunk(const R *src, int q0, int N, R *buf)
-{
-    if (sizeof(R) == 4 && q0 + kDtCH <= N) {
-        const float *srcf = reinterpret_cast<const float *>(src);
+        store(q0, out, ptr, aux_cur);
+        if (AUX) {
 #pragma unroll
-        for (int v = 0; v < kDtCH / 4; ++v) {
-            const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4 * v);
-            buf[4 * v] = a0.x; buf[4 * v + 1] = a0.y; buf[4 * v + 2] = a0.z; buf[4 * v + 3] = a0.w;
+            for (int i = 0; i < CH; ++i) aux_cur[i] = aux_nxt[i];
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < N) ? src[q0 + i] : (R)0;
     }
 }
+
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef short v8s_u __attribute__((ext_vector_type(8), aligned(2)));
+static_assert(kDtCH % 8 == 0, "the columns pass reads its int16 pointers 8 at a time");
 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
-// out: tmp TRANSPOSED ([x][y]: lanes are adjacent rows, every store instruction writes whole lines; the columns pass
-// reads its own column back contiguously) and the pointers Ix ROW-MAJOR ([y][x], 16 int16 per lane and store), which
-// is what the combine step reads: the reference's final Ix is the rows pass's pointer unchanged
-// (include/DistanceTransform.hpp:233-244).
-template <typename R, bool BZERO, int TAB, int NW>
+template <typename R>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
-    typedef DtRing<R, BZERO, TAB, NW> Ring;
-    __shared__ double invd[TAB > 0 ? TAB : 1];
-    __shared__ __attribute__((aligned(16))) char ring_mem[Ring::kLdsBytes];
-    Ring::fill_invd(invd);
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
     // the large levels are dispatched first and the tail of the launch is made of short ones
-    const int wv = blockIdx.z, lane = threadIdx.x;
+    const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv * 64 >= p.nrows_flat) return;
     const int r = wv * 64 + lane;
     const bool active = r < p.nrows_flat;
     const int rr = active ? r : p.nrows_flat - 1;
@@ -299,116 +208,119 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const R *src = (job.from_acc ? static_cast<const R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM
                                  : static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F) +
                    (size_t)job.plane * HW + (size_t)y * W;
+    // outputs go out TRANSPOSED ([x][y]): lanes are adjacent rows y, so every store instruction writes
+    // whole lines; the columns pass reads its own column back with wide per-lane loads
     const int Hl = d.rows;
-    const size_t jbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
-    R *tmpT = static_cast<R *>(p.tmp) + jbase + (size_t)y;
-    int16_t *ixr = p.IxRaw + jbase + (size_t)y * W;
-    __syncthreads();
-    Ring ring = Ring::make(ring_mem, lane, src, job.ax, job.bx, invd);
+    const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y;
+    R *tmpT = static_cast<R *>(p.tmp) + obase;
+    int16_t *ixT = p.IxT + obase;
+    __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
+    DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
+                                     reinterpret_cast<StkPairT<R> *>(p.stk) +
+                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane, job.ax, job.bx);
     const int N = active ? W : 0;
     if (N == 0) return;
-    auto load = [&](int q0, R *buf) { load_chunk<R>(src, q0, N, buf); };
-    auto store = [&](int q0, const R *out, const int *ptr) {
-#ifndef PBD_EXP_NO_TMP
+    auto load = [&](int q0, R *buf) {
+        if (sizeof(R) == 4 && q0 + kDtCH <= N) {
+            const float *srcf = reinterpret_cast<const float *>(src);
 #pragma unroll
-        for (int i = 0; i < kDtCH; ++i)
-            if (q0 + i < N) tmpT[(size_t)(q0 + i) * Hl] = out[i];
-#else
-        if (out[0] == (R)12345.678) tmpT[0] = out[1];
-#endif
-#ifdef PBD_EXP_NO_IX
-        if (ptr[0] == -77) ixr[0] = (int16_t)ptr[1];
-        return;
-#endif
-        if (q0 + kDtCH <= N) {
-#pragma unroll
-            for (int v = 0; v < kDtCH / 8; ++v) {
-                v8s_u t;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = (short)ptr[8 * v + e];
-                *reinterpret_cast<v8s_u *>(ixr + q0 + 8 * v) = t;
+            for (int v = 0; v < kDtCH / 4; ++v) {
+                const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4 * v);
+                buf[4 * v] = a0.x; buf[4 * v + 1] = a0.y; buf[4 * v + 2] = a0.z; buf[4 * v + 3] = a0.w;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < kDtCH; ++i)
-                if (q0 + i < N) ixr[q0 + i] = (int16_t)ptr[i];
+            for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < N) ? src[q0 + i] : (R)0;
         }
     };
-    dt_stream<R, Ring, BZERO, TAB>(N, job.osx, ring, load, store);
+    auto store = [&](int q0, const R *out, const int *ptr, const int *) {
+#pragma unroll
+        for (int i = 0; i < kDtCH; ++i)
+            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (int16_t)ptr[i]; }
+    };
+    auto noaux = [](int, int *) {};
+    dt_stream<R, false>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
 }
 
-// tab: entries of the 1/d table of the divide-free float intersection (0: divide); nw: words of the position mask
-// (both: the longest row / column must be shorter than 256 resp. 512); bzero: every job's linear coefficient in this
-// direction is exactly -0.0
-#define PBD_DT_LAUNCH(K)                                                                                        \
-    do {                                                                                                        \
-        if (f64) {                                                                                              \
-            if (wide) hipLaunchKernelGGL((K<double, false, 0, 16>), grid, dim3(64), 0, s, p);                   \
-            else hipLaunchKernelGGL((K<double, false, 0, 8>), grid, dim3(64), 0, s, p);                         \
-        } else if (nodiv && !wide) {                                                                            \
-            if (bzero) hipLaunchKernelGGL((K<float, true, 256, 8>), grid, dim3(64), 0, s, p);                   \
-            else hipLaunchKernelGGL((K<float, false, 256, 8>), grid, dim3(64), 0, s, p);                        \
-        } else if (nodiv) {                                                                                     \
-            if (bzero) hipLaunchKernelGGL((K<float, true, 512, 16>), grid, dim3(64), 0, s, p);                  \
-            else hipLaunchKernelGGL((K<float, false, 512, 16>), grid, dim3(64), 0, s, p);                       \
-        } else {                                                                                                \
-            if (wide) hipLaunchKernelGGL((K<float, false, 0, 16>), grid, dim3(64), 0, s, p);                    \
-            else hipLaunchKernelGGL((K<float, false, 0, 8>), grid, dim3(64), 0, s, p);                          \
-        }                                                                                                       \
-    } while (0)
-
-void launch_dt_rows(const DpParams &p, int nframes, bool f64, bool bzero, bool nodiv, bool wide, hipStream_t s)
+void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.JG == 0 || p.nrows_flat == 0) return;
-    dim3 grid(p.JG, nframes, (p.nrows_flat + 63) / 64);
-    PBD_DT_LAUNCH(k_dt_rows);
+    const int nwv = (p.nrows_flat + 63) / 64;
+    dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
+    if (f64) hipLaunchKernelGGL(k_dt_rows<double>, grid, dim3(64 * kDtWaves), 0, s, p);
+    else hipLaunchKernelGGL(k_dt_rows<float>, grid, dim3(64 * kDtWaves), 0, s, p);
 }
 
-// ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced outputs ----
-template <typename R, bool BZERO, int TAB, int NW>
+// ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
+template <typename R>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
 {
-    typedef DtRing<R, BZERO, TAB, NW> Ring;
-    __shared__ double invd[TAB > 0 ? TAB : 1];
-    __shared__ __attribute__((aligned(16))) char ring_mem[Ring::kLdsBytes];
-    Ring::fill_invd(invd);
-    const int wv = blockIdx.z, lane = threadIdx.x;   // longest columns first, as in the rows pass
+    const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // longest columns first, as in the rows pass
     const int cidx = wv * 64 + lane;
-    const bool active = cidx < p.ncols_flat;
-    const int cc = active ? cidx : p.ncols_flat - 1;
+    if (cidx >= p.ncols_flat) return;
     const int j = blockIdx.x, fl = blockIdx.y;
-    const int l = p.col2level[cc];
+    const int l = p.col2level[cidx];
     const LevelDesc d = p.lv[l];
-    const int x = cc - p.coloff[l];
-    const int H = active ? d.rows : 0, W = d.cols;
-    const size_t HW = (size_t)d.rows * W;
+    const int x = cidx - p.coloff[l];
+    const int H = d.rows, W = d.cols;
+    const size_t HW = (size_t)H * W;
     const DtJob job = p.jobs[j];
     const size_t jbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
-    const R *tmpT = static_cast<const R *>(p.tmp) + jbase + (size_t)x * d.rows;     // this lane's column, contiguous
+    const R *tmpT = static_cast<const R *>(p.tmp) + jbase + (size_t)x * H;     // this lane's column, contiguous
+    const int16_t *ixT = p.IxT + jbase + (size_t)x * H;
     R *dt = static_cast<R *>(p.dt) + jbase + x;
     int16_t *iyr = p.IyRaw + jbase + x;
-    __syncthreads();
-    Ring ring = Ring::make(ring_mem, lane, tmpT, job.ay, job.by, invd);
-    if (H == 0) return;
-    auto load = [&](int q0, R *buf) { load_chunk<R>(tmpT, q0, H, buf); };
-    auto store = [&](int q0, const R *out, const int *ptr) {
+    int16_t *ixr = p.IxRaw + jbase + x;
+    __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
+    DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
+                                     reinterpret_cast<StkPairT<R> *>(p.stk) +
+                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane, job.ay, job.by);
+    auto load = [&](int q0, R *buf) {
+        if (sizeof(R) == 4 && q0 + kDtCH <= H) {
+            const float *srcf = reinterpret_cast<const float *>(tmpT);
+#pragma unroll
+            for (int v = 0; v < kDtCH / 4; ++v) {
+                const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4 * v);
+                buf[4 * v] = a0.x; buf[4 * v + 1] = a0.y; buf[4 * v + 2] = a0.z; buf[4 * v + 3] = a0.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmpT[q0 + i] : (R)0;
+        }
+    };
+    auto aux = [&](int q0, int *buf) {      // the rows pass's pointers of this column
+        if (q0 + kDtCH <= H) {
+#pragma unroll
+            for (int v = 0; v < kDtCH / 8; ++v) {
+                const v8s_u a0 = *reinterpret_cast<const v8s_u *>(ixT + q0 + 8 * v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) buf[8 * v + e] = a0[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? ixT[q0 + i] : 0;
+        }
+    };
+    auto store = [&](int q0, const R *out, const int *ptr, const int *ix) {
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i)
             if (q0 + i < H) {
                 dt[(size_t)(q0 + i) * W] = out[i];
                 iyr[(size_t)(q0 + i) * W] = (int16_t)ptr[i];
+                ixr[(size_t)(q0 + i) * W] = (int16_t)ix[i];
             }
     };
-    dt_stream<R, Ring, BZERO, TAB>(H, job.osy, ring, load, store);
+    dt_stream<R, true>(H, job.ay, job.by, job.osy, ring, load, store, aux);
 }
 
-void launch_dt_cols(const DpParams &p, int nframes, bool f64, bool bzero, bool nodiv, bool wide, hipStream_t s)
+void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.JG == 0 || p.ncols_flat == 0) return;
-    dim3 grid(p.JG, nframes, (p.ncols_flat + 63) / 64);
-    PBD_DT_LAUNCH(k_dt_cols);
+    const int nwv = (p.ncols_flat + 63) / 64;
+    dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
+    if (f64) hipLaunchKernelGGL(k_dt_cols<double>, grid, dim3(64 * kDtWaves), 0, s, p);
+    else hipLaunchKernelGGL(k_dt_cols<float>, grid, dim3(64 * kDtWaves), 0, s, p);
 }
-#undef PBD_DT_LAUNCH
 
 // ---- combine: thread = 4 consecutive cells of one level, one PARENT part (block.y) ---------------------
 // For every parent mixture m: acc = response(parent, m); then for each child in descending index order
