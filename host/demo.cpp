@@ -3,7 +3,8 @@
 //   detect -> "Number of candidates" -> Candidate::sort [-> nonMaximaSuppression] -> list the best ones.
 // The GUI part of the reference's demo (Visualize, highgui) is out of scope.
 //
-//   pbd_demo model.yml image.(ppm|pgm) [--double] [--nms OVERLAP] [--top N] [--staged]
+//   pbd_demo model.(yml|xml) image.(ppm|pgm) [--double] [--nms OVERLAP] [--top N] [--staged]
+//   pbd_demo model.(yml|xml) --dump-model      (no GPU needed: prints what FileStorageModel::deserialize read)
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -49,6 +50,39 @@ static int run(FileStorageModel &model, const Image &im, bool staged, float nms,
     return 0;
 }
 
+// every field FileStorageModel::deserialize fills, as text (doubles with 17 significant digits: exact round trip)
+static int dump_model(const FileStorageModel &m)
+{
+    std::printf("name %s\ninterval %d\nthresh %.9g\nsbin %d\nnorient %d\nflen %d\n", m.name().c_str(), m.nscales(), (double)m.thresh(),
+                m.binsize(), m.norient(), m.flen());
+    for (size_t f = 0; f < m.filtersw_.size(); ++f) {
+        std::printf("filter %zu %d %d", f, m.filtersw_[f].rows, m.filtersw_[f].cols);
+        for (size_t i = 0; i < m.filtersw_[f].data.size(); ++i) std::printf(" %.17g", m.filtersw_[f].data[i]);
+        std::printf("\n");
+    }
+    std::printf("biasw");
+    for (size_t i = 0; i < m.biasw_.size(); ++i) std::printf(" %.9g", (double)m.biasw_[i]);
+    std::printf("\nanchors");
+    for (size_t i = 0; i < m.anchors_.size(); ++i) std::printf(" %d,%d", m.anchors_[i].first, m.anchors_[i].second);
+    std::printf("\n");
+    for (size_t d = 0; d < m.defw_.size(); ++d) {
+        std::printf("def %zu", d);
+        for (size_t i = 0; i < m.defw_[d].size(); ++i) std::printf(" %.9g", (double)m.defw_[d][i]);
+        std::printf("\n");
+    }
+    for (size_t c = 0; c < m.filterid_.size(); ++c)
+        for (size_t p = 0; p < m.filterid_[c].size(); ++p) {
+            std::printf("part %zu %zu parent %d filterid", c, p, m.parentid_[c][p]);
+            for (size_t i = 0; i < m.filterid_[c][p].size(); ++i) std::printf(" %d", m.filterid_[c][p][i]);
+            std::printf(" biasid");
+            for (size_t i = 0; i < m.biasid_[c][p].size(); ++i) std::printf(" %d", m.biasid_[c][p][i]);
+            std::printf(" defid");
+            for (size_t i = 0; i < m.defid_[c][p].size(); ++i) std::printf(" %d", m.defid_[c][p][i]);
+            std::printf("\n");
+        }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 3) {
@@ -67,6 +101,7 @@ int main(int argc, char **argv)
     try {
         FileStorageModel model;
         if (!model.deserialize(argv[1])) { std::fprintf(stderr, "Error deserializing file\n"); return -1; }
+        if (!std::strcmp(argv[2], "--dump-model")) return dump_model(model);
         std::vector<uint8_t> pix;
         Image im;
         if (!readPNM(argv[2], pix, im)) { std::fprintf(stderr, "Image not found, or invalid image format\n"); return -1; }

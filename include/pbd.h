@@ -153,6 +153,15 @@ int pbd_detect(pbd_handle *h, const void *img, int rows, int cols, int channels,
  * nframes pbd_detect calls, candidate `frame` field = index in the batch. */
 int pbd_detect_batch(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int channels,
                      size_t stride_bytes, int32_t *cand, int capacity, int *ncand);
+/* Pipelined form of pbd_detect_batch (new surface, as the batch API): submit() copies the frames into a pinned
+ * staging buffer of the handle, starts their transfer on a copy stream and enqueues the whole path behind it, without
+ * waiting; wait() returns the candidates of the oldest submitted batch (same records and order as pbd_detect_batch).
+ * Up to two batches may be in flight -- submit(k+1), then wait(k) -- so that the host-side staging and the PCIe
+ * transfer of batch k+1 overlap the kernels of batch k.  The synchronous entry points and the staged read-back
+ * refuse to run (PBD_ERR_STATE) while a batch is in flight. */
+int pbd_detect_batch_submit(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int channels,
+                            size_t stride_bytes);
+int pbd_detect_batch_wait(pbd_handle *h, int32_t *cand, int capacity, int *ncand);
 /* Same, frames already resident in device memory: d_frames = nframes contiguous rows*cols*channels
  * images.  cand is a HOST buffer. */
 int pbd_detect_batch_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels,

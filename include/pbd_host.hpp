@@ -244,24 +244,110 @@ class FileStorageModel : public Model {
         return std::vector<int>(v.begin(), v.end());
     }
 
+    // ---- the <opencv_storage> XML flavour (what the reference's configs name: conf/config_person.by_parts:30,
+    // conf/config_face.by_parts:31).  Elements with children become maps (sequences when every child is <_>),
+    // leaves become scalars or, with several whitespace-separated tokens, sequences; attributes are not needed
+    // (an opencv-matrix is recognised by its rows / cols / data children).
+    static void xml_skip(const std::string &t, size_t &p)
+    {   // whitespace, comments, processing instructions
+        for (;;) {
+            while (p < t.size() && (t[p] == ' ' || t[p] == '\n' || t[p] == '\r' || t[p] == '\t')) ++p;
+            if (t.compare(p, 4, "<!--") == 0) { const size_t e = t.find("-->", p); p = e == std::string::npos ? t.size() : e + 3; continue; }
+            if (t.compare(p, 2, "<?") == 0) { const size_t e = t.find("?>", p); p = e == std::string::npos ? t.size() : e + 2; continue; }
+            return;
+        }
+    }
+    static Node xml_leaf(const std::string &text)
+    {
+        const std::string body = trim_ws(text);
+        Node n;
+        if (body.empty()) return n;
+        if (body[0] == '"') { n.scalar = body.substr(1, body.rfind('"') - 1); return n; }
+        std::vector<std::string> toks;
+        std::istringstream is(body);
+        for (std::string tk; is >> tk;) toks.push_back(tk);
+        if (toks.size() == 1) { n.scalar = toks[0]; return n; }
+        n.is_seq = true;
+        for (size_t i = 0; i < toks.size(); ++i) { Node e; e.scalar = toks[i]; n.seq.push_back(e); }
+        return n;
+    }
+    static std::string trim_ws(const std::string &s)
+    {
+        size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+        return a == std::string::npos ? "" : s.substr(a, b - a + 1);
+    }
+    // parses the element starting at t[p] == '<'; returns its tag and value
+    static Node xml_element(const std::string &t, size_t &p, std::string &tag)
+    {
+        if (p >= t.size() || t[p] != '<') throw Error(PBD_ERR_INVALID, "model file: malformed XML");
+        const size_t gt = t.find('>', p);
+        if (gt == std::string::npos) throw Error(PBD_ERR_INVALID, "model file: unterminated XML tag");
+        std::string head = t.substr(p + 1, gt - p - 1);
+        const bool self_closed = !head.empty() && head[head.size() - 1] == '/';
+        if (self_closed) head.erase(head.size() - 1);
+        tag = head.substr(0, head.find_first_of(" \t\r\n"));
+        p = gt + 1;
+        Node n;
+        if (self_closed) return n;
+        std::string text;
+        std::vector<std::pair<std::string, Node> > kids;
+        for (;;) {
+            const size_t lt = t.find('<', p);
+            if (lt == std::string::npos) throw Error(PBD_ERR_INVALID, "model file: unterminated XML element <" + tag + ">");
+            text += t.substr(p, lt - p);
+            p = lt;
+            if (t.compare(p, 4, "<!--") == 0) { xml_skip(t, p); continue; }
+            if (t.compare(p, 2, "</") == 0) { p = t.find('>', p) + 1; break; }
+            std::string ktag;
+            Node kid = xml_element(t, p, ktag);
+            kids.push_back(std::make_pair(ktag, kid));
+        }
+        if (kids.empty()) return xml_leaf(text);
+        bool all_items = true;
+        for (size_t i = 0; i < kids.size(); ++i) all_items = all_items && kids[i].first == "_";
+        if (all_items) { n.is_seq = true; for (size_t i = 0; i < kids.size(); ++i) n.seq.push_back(kids[i].second); }
+        else { n.is_map = true; n.map = kids; }
+        return n;
+    }
+    static Node xml_document(const std::string &t)
+    {
+        size_t p = 0;
+        xml_skip(t, p);
+        std::string tag;
+        Node root = xml_element(t, p, tag);
+        if (tag != "opencv_storage") throw Error(PBD_ERR_INVALID, "model file: root element <" + tag + "> is not <opencv_storage>");
+        return root;
+    }
+
 public:
     bool deserialize(const std::string &filename)
     {   // src/FileStorageModel.cpp:96-159
         std::ifstream in(filename.c_str());
         if (!in) return false;
-        std::vector<std::string> raw, L;
-        for (std::string ln; std::getline(in, ln);) {
-            if (!ln.empty() && ln[0] == '%') continue;
-            if (trim(ln).empty() || trim(ln) == "---") continue;
-            raw.push_back(ln);
+        std::stringstream whole;
+        whole << in.rdbuf();
+        const std::string text = whole.str();
+        const size_t first = text.find_first_not_of(" \t\r\n");
+        const bool is_xml = first != std::string::npos && text[first] == '<';
+        Node doc;
+        if (is_xml) {
+            doc = xml_document(text);
+        } else {
+            std::vector<std::string> raw, L;
+            std::istringstream lines(text);
+            for (std::string ln; std::getline(lines, ln);) {
+                if (!ln.empty() && ln[0] == '%') continue;
+                if (trim(ln).empty() || trim(ln) == "---") continue;
+                raw.push_back(ln);
+            }
+            int depth = 0;   // join flow sequences wrapped over several lines
+            for (size_t i = 0; i < raw.size(); ++i) {
+                if (depth == 0) L.push_back(raw[i]); else L.back() += " " + trim(raw[i]);
+                for (size_t k = 0; k < raw[i].size(); ++k) depth += (raw[i][k] == '[') - (raw[i][k] == ']');
+            }
+            size_t i = 0;
+            doc = block(L, i, 0);
         }
-        int depth = 0;   // join flow sequences wrapped over several lines
-        for (size_t i = 0; i < raw.size(); ++i) {
-            if (depth == 0) L.push_back(raw[i]); else L.back() += " " + trim(raw[i]);
-            for (size_t k = 0; k < raw[i].size(); ++k) depth += (raw[i][k] == '[') - (raw[i][k] == ']');
-        }
-        size_t i = 0;
-        const Node doc = block(L, i, 0);
         name_ = doc.has("name") ? doc["name"].scalar : "";
         nscales_ = (int)doc["interval"].num();
         thresh_ = (float)doc["thresh"].num();

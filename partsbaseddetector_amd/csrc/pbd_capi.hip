@@ -212,6 +212,18 @@ struct pbd_handle {
     DevBuf tmp, dt, IxT, IxRaw, IyRaw, stk, cand, count, scales_tmp;
     std::vector<int32_t> cand_host;
 
+    // pipelined host entry points (pbd_detect_batch_submit / _wait): two batches may be in flight
+    struct Slot {
+        void *pinned = nullptr; size_t pinned_cap = 0;   // host staging of the frames (hipHostMalloc)
+        DevBuf frames, cand, count;
+        int *count_host = nullptr;                        // pinned
+        hipEvent_t copied = nullptr, done = nullptr;
+        Plan *plan = nullptr;
+        int nframes = 0;
+    } slot[2];
+    hipStream_t stream_copy = nullptr, stream_d2h = nullptr;
+    long long nsubmitted = 0, nwaited = 0;
+
     Prof prof;
 };
 
@@ -929,13 +941,8 @@ int run_dp(pbd_handle *h, Plan &P, int nframes)
     return PBD_OK;
 }
 
-int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32_t *cand, int capacity, int *ncand)
+ArgminParams argmin_params(pbd_handle *h, Plan &P, int nframes, const float *d_scales, DevBuf &cand, DevBuf &count)
 {
-    const int stride = 8 + 4 * h->max_parts;
-    const int cap = std::max(h->cfg.max_candidates, 1);
-    HIPCHK(h, h->cand.ensure((size_t)cap * stride * sizeof(int32_t)));
-    HIPCHK(h, h->count.ensure(sizeof(int)));
-    HIPCHK(h, hipMemsetAsync(h->count.p, 0, sizeof(int), h->stream));
     ArgminParams ap{};
     ap.lv = P.d_lv.d; ap.nlevels = P.nlevels; ap.NS = h->NS; ap.NC = h->NC; ap.nframes = nframes;
     ap.cell_per_frame = P.cell_per_frame;
@@ -943,29 +950,18 @@ int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32
     ap.Ix = h->Ix.as<int16_t>(); ap.Iy = h->Iy.as<int16_t>(); ap.Ik = h->Ik.as<uint8_t>();
     ap.thresh = h->thresh; ap.scales = d_scales;
     ap.walk = h->d_walk.d; ap.walk_off = h->d_walk_off.d;
-    ap.max_parts = h->max_parts; ap.stride = stride; ap.capacity = cap;
-    ap.count = h->count.as<int>(); ap.cand = h->cand.as<int32_t>();
-    int found = 0;
-    {
-        ProfScope ps(h, PBD_K_ARGMIN, h->stream);
-        launch_argmin_find(ap, h->f64, h->stream);
-    }
-    HIPCHK(h, hipMemcpyAsync(&found, h->count.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const bool dev_overflow = found > cap;
+    ap.max_parts = h->max_parts; ap.stride = 8 + 4 * h->max_parts; ap.capacity = std::max(h->cfg.max_candidates, 1);
+    ap.count = count.as<int>(); ap.cand = cand.as<int32_t>();
+    return ap;
+}
+
+// the host half of argmin: `n` records in h->cand_host -> total order (frame, level, component, y, x) -> caller's buffer
+// (the reference's order is nondeterministic: src/DynamicProgram.cpp:246-251)
+int argmin_deliver(pbd_handle *h, int found, int32_t *cand, int capacity, int *ncand)
+{
+    const int stride = 8 + 4 * h->max_parts;
+    const int cap = std::max(h->cfg.max_candidates, 1);
     const int n = std::min(found, cap);
-    if (n > 0) {
-        {
-            ProfScope ps(h, PBD_K_ARGMIN, h->stream);
-            launch_argmin_walk(ap, n, h->f64, h->stream);
-        }
-        h->cand_host.resize((size_t)n * stride);
-        HIPCHK(h, hipMemcpyAsync(h->cand_host.data(), h->cand.p, (size_t)n * stride * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                 h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
-    HIPCHK(h, hipGetLastError());
-    // total order (frame, level, component, y, x); the reference's order is nondeterministic
     std::vector<int> order(n);
     std::iota(order.begin(), order.end(), 0);
     const int32_t *ch = h->cand_host.data();
@@ -981,15 +977,44 @@ int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32
     for (int i = 0; i < nout; ++i)
         memcpy(cand + (size_t)i * stride, ch + (size_t)order[i] * stride, (size_t)stride * sizeof(int32_t));
     *ncand = nout;
-    if (dev_overflow || n > capacity)
+    if (found > cap || n > capacity)
         return fail(h, PBD_ERR_CAPACITY, "%d candidates found, capacity %d (config max_candidates %d)", found, capacity, cap);
     return PBD_OK;
 }
 
-int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int cn, int32_t *cand,
-                  int capacity, int *ncand)
+int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32_t *cand, int capacity, int *ncand)
 {
-    if (!h || !cand || !ncand) return PBD_ERR_INVALID;
+    const int stride = 8 + 4 * h->max_parts;
+    const int cap = std::max(h->cfg.max_candidates, 1);
+    HIPCHK(h, h->cand.ensure((size_t)cap * stride * sizeof(int32_t)));
+    HIPCHK(h, h->count.ensure(sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(h->count.p, 0, sizeof(int), h->stream));
+    const ArgminParams ap = argmin_params(h, P, nframes, d_scales, h->cand, h->count);
+    int found = 0;
+    {
+        ProfScope ps(h, PBD_K_ARGMIN, h->stream);
+        launch_argmin_find(ap, h->f64, h->stream);
+    }
+    HIPCHK(h, hipMemcpyAsync(&found, h->count.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int n = std::min(found, cap);
+    if (n > 0) {
+        {
+            ProfScope ps(h, PBD_K_ARGMIN, h->stream);
+            launch_argmin_walk(ap, n, h->f64, h->stream);
+        }
+        h->cand_host.resize((size_t)n * stride);
+        HIPCHK(h, hipMemcpyAsync(h->cand_host.data(), h->cand.p, (size_t)n * stride * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                 h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(h, hipGetLastError());
+    return argmin_deliver(h, found, cand, capacity, ncand);
+}
+
+// enqueues pyramid -> HOG -> convolution -> dynamic program for the batch (no host synchronisation); *plan_out = its plan
+int enqueue_detect(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int cn, Plan **plan_out)
+{
     if (nframes < 1 || nframes > h->cfg.max_batch)
         return fail(h, PBD_ERR_INVALID, "nframes %d outside 1..max_batch %d", nframes, h->cfg.max_batch);
     if (cn != 1 && cn != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", cn);
@@ -1040,6 +1065,18 @@ int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, in
     }
     HIPCHK(h, hipGetLastError());
     h->have_features = h->have_resp = h->have_dp = true;
+    *plan_out = P;
+    return PBD_OK;
+}
+
+int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int cn, int32_t *cand,
+                  int capacity, int *ncand)
+{
+    if (!h || !cand || !ncand) return PBD_ERR_INVALID;
+    if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
+    Plan *P = nullptr;
+    const int rc = enqueue_detect(h, nframes, d_frames, rows, cols, cn, &P);
+    if (rc != PBD_OK) return rc;
     return run_argmin(h, *P, nframes, P->d_scales.d, cand, capacity, ncand);
 }
 
@@ -1141,6 +1178,17 @@ void pbd_destroy(pbd_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     h->prof.release();
+    if (h->stream_copy) (void)hipStreamSynchronize(h->stream_copy);
+    if (h->stream_d2h) (void)hipStreamSynchronize(h->stream_d2h);
+    for (pbd_handle::Slot &S : h->slot) {
+        if (S.pinned) (void)hipHostFree(S.pinned);
+        if (S.count_host) (void)hipHostFree(S.count_host);
+        if (S.copied) (void)hipEventDestroy(S.copied);
+        if (S.done) (void)hipEventDestroy(S.done);
+        S.frames.release(); S.cand.release(); S.count.release();
+    }
+    if (h->stream_copy) (void)hipStreamDestroy(h->stream_copy);
+    if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
     for (auto e : h->chunk_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (DevBuf *b : {&h->frames, &h->pyr, &h->gmag, &h->gori, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
@@ -1194,6 +1242,7 @@ int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int
 {
     return guarded(h, [&]() -> int {
         if (!h || !img || !feat) return PBD_ERR_INVALID;
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
         (void)hipSetDevice(h->cfg.device);
         if (depth_code != 0) return fail(h, PBD_ERR_UNSUPPORTED, "image depth code %d: only 8-bit unsigned is supported", depth_code);
         if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
@@ -1220,6 +1269,7 @@ int pbd_get_pyramid_image(pbd_handle *h, int frame, int level, uint8_t *dst)
 {
     return guarded(h, [&]() -> int {
         if (!h || !dst) return PBD_ERR_INVALID;
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
         (void)hipSetDevice(h->cfg.device);
         if (!h->cur || h->cur->kind != 0 || !h->have_features) return fail(h, PBD_ERR_STATE, "no pyramid has been computed");
         Plan &P = *h->cur;
@@ -1236,6 +1286,7 @@ int pbd_conv_set_filters(pbd_handle *h, int nfilters, const void *const *filters
 {
     return guarded(h, [&]() -> int {
         if (!h || !filters || !ksize) return PBD_ERR_INVALID;
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
         (void)hipSetDevice(h->cfg.device);
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
@@ -1250,6 +1301,7 @@ int pbd_conv_pdf(pbd_handle *h, int nlevels, const void *const *feat, const int 
 {
     return guarded(h, [&]() -> int {
         if (!h || !feat || !rows || !cols || !resp) return PBD_ERR_INVALID;
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
         (void)hipSetDevice(h->cfg.device);
         Plan *P = nullptr;
         int rc = get_dims_plan(h, nlevels, rows, cols, &P);
@@ -1277,6 +1329,7 @@ int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, con
 {
     return guarded(h, [&]() -> int {
         if (!h || !rows || !cols || !resp) return PBD_ERR_INVALID;
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
         (void)hipSetDevice(h->cfg.device);
         Plan *P = nullptr;
         if (!h->bank_matches_model)
@@ -1325,6 +1378,7 @@ int pbd_dp_argmin(pbd_handle *h, const float *scales, int32_t *cand, int capacit
 {
     return guarded(h, [&]() -> int {
         if (!h || !scales || !cand || !ncand) return PBD_ERR_INVALID;
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
         (void)hipSetDevice(h->cfg.device);
         if (!h->cur || !h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
         Plan &P = *h->cur;
@@ -1355,6 +1409,83 @@ int pbd_detect_batch(pbd_handle *h, int nframes, const void *const *imgs, int ro
     });
 }
 
+int pbd_detect_batch_submit(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int channels,
+                            size_t stride_bytes)
+{
+    return guarded(h, [&]() -> int {
+        if (!h || !imgs) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (h->nsubmitted - h->nwaited >= 2) return fail(h, PBD_ERR_STATE, "two batches are already in flight: call pbd_detect_batch_wait first");
+        if (nframes < 1 || nframes > h->cfg.max_batch)
+            return fail(h, PBD_ERR_INVALID, "nframes %d outside 1..max_batch %d", nframes, h->cfg.max_batch);
+        if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
+        const size_t row_bytes = (size_t)cols * channels, frame_bytes = row_bytes * rows, bytes = frame_bytes * nframes;
+        if (stride_bytes < row_bytes) return fail(h, PBD_ERR_INVALID, "stride %zu < row bytes %zu", stride_bytes, row_bytes);
+        pbd_handle::Slot &S = h->slot[h->nsubmitted & 1];
+        if (!h->stream_copy) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
+        if (!h->stream_d2h) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
+        if (!S.copied) HIPCHK(h, hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
+        if (!S.done) HIPCHK(h, hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+        if (!S.count_host) HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&S.count_host), sizeof(int), hipHostMallocDefault));
+        if (S.pinned_cap < bytes) {
+            if (S.pinned) { (void)hipHostFree(S.pinned); S.pinned = nullptr; S.pinned_cap = 0; }
+            HIPCHK(h, hipHostMalloc(&S.pinned, bytes + bytes / 8, hipHostMallocDefault));
+            S.pinned_cap = bytes + bytes / 8;
+        }
+        HIPCHK(h, S.frames.ensure(bytes));
+        const int stride = 8 + 4 * h->max_parts, cap = std::max(h->cfg.max_candidates, 1);
+        HIPCHK(h, S.cand.ensure((size_t)cap * stride * sizeof(int32_t)));
+        HIPCHK(h, S.count.ensure(sizeof(int)));
+        // host staging (this is what overlaps the kernels of the batch submitted before), then one asynchronous copy
+        for (int i = 0; i < nframes; ++i) {
+            char *dst = static_cast<char *>(S.pinned) + (size_t)i * frame_bytes;
+            const char *src = static_cast<const char *>(imgs[i]);
+            if (stride_bytes == row_bytes) memcpy(dst, src, frame_bytes);
+            else for (int y = 0; y < rows; ++y) memcpy(dst + (size_t)y * row_bytes, src + (size_t)y * stride_bytes, row_bytes);
+        }
+        HIPCHK(h, hipMemcpyAsync(S.frames.p, S.pinned, bytes, hipMemcpyHostToDevice, h->stream_copy));
+        HIPCHK(h, hipEventRecord(S.copied, h->stream_copy));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, S.copied, 0));
+        Plan *P = nullptr;
+        int rc = enqueue_detect(h, nframes, S.frames.p, rows, cols, channels, &P);
+        if (rc != PBD_OK) return rc;
+        HIPCHK(h, hipMemsetAsync(S.count.p, 0, sizeof(int), h->stream));
+        const ArgminParams ap = argmin_params(h, *P, nframes, P->d_scales.d, S.cand, S.count);
+        {
+            ProfScope ps(h, PBD_K_ARGMIN, h->stream);
+            launch_argmin_find(ap, h->f64, h->stream);
+            launch_argmin_walk(ap, -1, h->f64, h->stream);     // count read on the device
+        }
+        HIPCHK(h, hipMemcpyAsync(S.count_host, S.count.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipEventRecord(S.done, h->stream));
+        HIPCHK(h, hipGetLastError());
+        S.plan = P; S.nframes = nframes;
+        h->nsubmitted += 1;
+        return PBD_OK;
+    });
+}
+
+int pbd_detect_batch_wait(pbd_handle *h, int32_t *cand, int capacity, int *ncand)
+{
+    return guarded(h, [&]() -> int {
+        if (!h || !cand || !ncand) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (h->nsubmitted == h->nwaited) return fail(h, PBD_ERR_STATE, "no batch in flight");
+        pbd_handle::Slot &S = h->slot[h->nwaited & 1];
+        h->nwaited += 1;                       // the slot is released whatever happens below
+        HIPCHK(h, hipEventSynchronize(S.done));
+        const int stride = 8 + 4 * h->max_parts, cap = std::max(h->cfg.max_candidates, 1);
+        const int found = *S.count_host, n = std::min(found, cap);
+        h->cand_host.resize((size_t)n * stride);
+        if (n > 0) {
+            HIPCHK(h, hipMemcpyAsync(h->cand_host.data(), S.cand.p, (size_t)n * stride * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                     h->stream_d2h));
+            HIPCHK(h, hipStreamSynchronize(h->stream_d2h));
+        }
+        return argmin_deliver(h, found, cand, capacity, ncand);
+    });
+}
+
 int pbd_detect_batch_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels,
                             int32_t *cand, int capacity, int *ncand)
 {
@@ -1369,6 +1500,7 @@ int pbd_get_stage(pbd_handle *h, int stage, int frame, int level, void *dst, siz
 {
     return guarded(h, [&]() -> int {
         if (!h || !dst) return PBD_ERR_INVALID;
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
         (void)hipSetDevice(h->cfg.device);
         if (!h->cur) return fail(h, PBD_ERR_STATE, "nothing has been computed");
         Plan &P = *h->cur;

@@ -14,6 +14,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 namespace pbd {
 
 template <typename R>
@@ -560,11 +562,13 @@ template <> __device__ __forceinline__ int round_mul<float>(int a, float s) { re
 template <> __device__ __forceinline__ int round_mul<double>(int a, double s) { return __double2int_rn((double)a * s); }
 
 // walk: one thread per candidate follows Ix/Iy/Ik from the root (src/DynamicProgram.cpp:218-244)
+// ncand < 0: the number of candidates is read from the device counter (pipelined entry points: the host does not
+// know it yet); the grid then strides over min(count, capacity) records
 template <typename R>
 __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ncand) return;
+    if (ncand < 0) ncand = min(*p.count, p.capacity);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncand; i += gridDim.x * blockDim.x) {
     int32_t *rec = p.cand + (size_t)i * p.stride;
     const int frame = rec[0], c = rec[1], l = rec[2];
     const LevelDesc d = p.lv[l];
@@ -601,13 +605,15 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
     }
     rec[6] = nparts;
     rec[7] = 0;
+    }
 }
 
 void launch_argmin_walk(const ArgminParams &p, int ncand, bool f64, hipStream_t s)
 {
     if (ncand == 0) return;
-    if (f64) hipLaunchKernelGGL(k_argmin_walk<double>, dim3((ncand + 63) / 64), dim3(64), 0, s, p, ncand);
-    else hipLaunchKernelGGL(k_argmin_walk<float>, dim3((ncand + 63) / 64), dim3(64), 0, s, p, ncand);
+    const int blocks = ncand < 0 ? std::min((p.capacity + 63) / 64, 4096) : (ncand + 63) / 64;
+    if (f64) hipLaunchKernelGGL(k_argmin_walk<double>, dim3(blocks), dim3(64), 0, s, p, ncand);
+    else hipLaunchKernelGGL(k_argmin_walk<float>, dim3(blocks), dim3(64), 0, s, p, ncand);
 }
 
 }  // namespace pbd

@@ -323,6 +323,26 @@ class PartsBasedDetector:
                                                    buf.ctypes.data, cap, C.byref(n)))
         return self.hd.unpack_candidates(buf, n.value)
 
+    def submit_batch(self, frames: Sequence[np.ndarray]) -> None:
+        """pbd_detect_batch_submit: stage + transfer + enqueue the whole path for `frames` without waiting (at most
+        two batches in flight); `wait_batch` returns the results in submission order."""
+        self._need()
+        fr = [np.ascontiguousarray(f if f.ndim == 3 else f[:, :, None], np.uint8) for f in frames]
+        rows, cols, cn = fr[0].shape
+        assert all(f.shape == fr[0].shape for f in fr), "a batch holds equally sized frames"
+        self.hd.check(self.hd.lib.pbd_detect_batch_submit(self.hd.h, len(fr), _lib.ptr_array(fr), rows, cols, cn, cols * cn))
+
+    def wait_batch(self, capacity: Optional[int] = None, raw: bool = False):
+        self._need()
+        cap = capacity or self.hd.max_candidates
+        if not hasattr(self, "_buf") or self._buf.size < cap * self.hd.stride:
+            self._buf = np.zeros(cap * self.hd.stride, np.int32)
+        n = C.c_int()
+        self.hd.check(self.hd.lib.pbd_detect_batch_wait(self.hd.h, self._buf.ctypes.data, cap, C.byref(n)))
+        if raw:
+            return self._buf, n.value
+        return self.hd.unpack_candidates(self._buf, n.value)
+
     def detect_batch_device(self, d_frames_ptr: int, nframes: int, rows: int, cols: int, cn: int,
                             capacity: Optional[int] = None, raw: bool = False):
         """frames already resident in device memory (e.g. a torch uint8 tensor's data_ptr())."""

@@ -68,6 +68,45 @@ def serialize(model: Model, filename: str) -> bool:
     return True
 
 
+def serialize_xml(model: Model, filename: str) -> bool:
+    """The same document in the layout OpenCV's XML writer produces (`fs.open("model.xml", WRITE)`): an
+    <opencv_storage> root, sequences of <_> items, `type_id="opencv-matrix"` nodes, numbers wrapped over lines.
+    The reference's configs name XML models (conf/config_person.by_parts:30, conf/config_face.by_parts:31)."""
+    def wrap(vals, indent, per_line=4):
+        toks = [_fmt(v) for v in vals]
+        pad = " " * indent
+        return "\n".join(pad + " ".join(toks[i:i + per_line]) for i in range(0, len(toks), per_line))
+    out = ['<?xml version="1.0"?>', "<opencv_storage>", f'<name>"{model.name}"</name>' if " " in model.name else f"<name>{model.name}</name>",
+           f"<interval>{model.interval}</interval>", f"<thresh>{_fmt(float(model.thresh))}</thresh>", f"<sbin>{model.sbin}</sbin>",
+           f"<norient>{model.norient}</norient>", f"<flen>{model.flen}</flen>", "<filtersw>"]
+    for f in model.filtersw:
+        f = np.asarray(f, np.float64)
+        out += ['  <_ type_id="opencv-matrix">', f"    <rows>{f.shape[0]}</rows>", f"    <cols>{f.shape[1]}</cols>", "    <dt>d</dt>",
+                "    <data>", wrap(f.ravel(), 6) + "</data></_>"]
+    out[-1] += "</filtersw>"
+    out += ["<biasw>", wrap([float(np.float32(b)) for b in model.biasw], 2, 6) + "</biasw>"]
+    out += ["<anchors>", wrap([int(v) for a in model.anchors for v in a], 2, 10) + "</anchors>"]
+    out.append("<defs>")
+    for d in model.defw:
+        out += ["  <_>", wrap([float(np.float32(v)) for v in d], 4) + "</_>"]
+    out[-1] += "</defs>"
+    out.append("<indexers>")
+    for c in range(model.ncomponents()):
+        out.append(f"  <component-{c}>")
+        for p in range(model.nparts(c)):
+            out.append(f"    <part-{p}>")
+            out.append(f"      <parentid>{model.parentid[c][p]}</parentid>")
+            for key, vals in (("filterid", model.filterid[c][p]), ("biasid", model.biasid[c][p]), ("defid", model.defid[c][p])):
+                out += [f"      <{key}>", wrap(vals, 8, 10) + f"</{key}>"] if len(vals) else [f"      <{key}></{key}>"]
+            out[-1] += f"</part-{p}>"
+        out[-1] += f"</component-{c}>"
+    out[-1] += "</indexers>"
+    out.append("</opencv_storage>")
+    with open(filename, "w") as fh:
+        fh.write("\n".join(out) + "\n")
+    return True
+
+
 # ------------------------------------------------------------------------------------------ YAML reader
 def _scalar(tok: str):
     tok = tok.strip()

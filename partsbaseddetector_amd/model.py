@@ -49,27 +49,40 @@ class Model:
         return len(self.filtersw)
 
     def validate(self) -> None:
-        assert self.norient == 18, "the reference's uu/vv tables hold 9 orientations (src/HOGFeatures.cpp:192-193)"
-        assert self.flen >= self.norient + self.norient // 2 + 5
+        """Structural checks before the tables reach pbd_create / the oracle; raises ValueError (never `assert`, which
+        `python -O` strips)."""
+        def need(cond, msg):
+            if not cond:
+                raise ValueError(f"model {self.name!r}: {msg}")
+        need(self.norient == 18, "the reference's uu/vv tables hold 9 orientations (src/HOGFeatures.cpp:192-193): norient must be 18")
+        need(self.flen >= self.norient + self.norient // 2 + 5, f"flen {self.flen} too small for norient {self.norient}")
+        need(self.ncomponents() >= 1 and len(self.filtersw) >= 1, "no components / filters")
+        need(len(self.biasid) == len(self.defid) == len(self.parentid) == self.ncomponents(), "indexer tables differ in length")
         for f in self.filtersw:
-            k = f.shape[0]
-            assert f.shape == (k, k * self.flen), f.shape
+            f = np.asarray(f)
+            need(f.ndim == 2 and f.shape[0] >= 1 and f.shape == (f.shape[0], f.shape[0] * self.flen), f"filter shape {f.shape}")
         for c in range(self.ncomponents()):
-            seen = set()
-            for p in range(self.nparts(c)):
+            np_c = self.nparts(c)
+            need(np_c >= 1 and len(self.biasid[c]) == len(self.defid[c]) == len(self.parentid[c]) == np_c,
+                 f"component {c}: indexer tables differ in length")
+            for p in range(np_c):
                 par = self.parentid[c][p]
-                assert (par == -1 and p == 0) or (0 <= par < p), "parts must be topologically ordered"
+                need((par == -1 and p == 0) or (p > 0 and 0 <= par < p), f"component {c} part {p}: parent {par} breaks the topological order")
+                need(len(self.filterid[c][p]) >= 1, f"component {c} part {p} has no mixtures")
                 for f in self.filterid[c][p]:
-                    assert 0 <= f < len(self.filtersw)
-                    assert f not in seen, "a filter id may be used once per component"
-                    seen.add(f)
+                    need(0 <= f < len(self.filtersw), f"component {c} part {p}: filter id {f} out of range")
                 if p > 0:
                     K = len(self.filterid[c][p])
                     L = len(self.filterid[c][par])
-                    assert len(self.defid[c][p]) >= K and len(self.biasid[c][p]) >= K
+                    need(len(self.defid[c][p]) >= K and len(self.biasid[c][p]) >= K,
+                         f"component {c} part {p}: {K} mixtures but {len(self.defid[c][p])} defids / {len(self.biasid[c][p])} biasids")
                     for mm in range(K):
-                        assert 0 <= self.defid[c][p][mm] < len(self.defw)
-                        assert 0 <= self.biasid[c][p][mm] and self.biasid[c][p][mm] + L <= len(self.biasw)
+                        need(0 <= self.defid[c][p][mm] < len(self.defw), f"component {c} part {p}: defid {self.defid[c][p][mm]} out of range")
+                        need(len(self.anchors) >= len(self.defw), "fewer anchors than deformations")
+                        need(0 <= self.biasid[c][p][mm] and self.biasid[c][p][mm] + L <= len(self.biasw),
+                             f"component {c} part {p}: biasid {self.biasid[c][p][mm]} out of range")
+                else:
+                    need(len(self.biasid[c][p]) >= 1 and 0 <= self.biasid[c][p][0] < len(self.biasw), f"component {c}: root biasid out of range")
 
     def flatten(self) -> "FlatModel":
         return FlatModel(self)

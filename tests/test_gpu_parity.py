@@ -513,3 +513,37 @@ def test_config2_gpu_features_conv_host_dp(det_mod, oracle):
     det.distributeModel(model)
     _compare_candidates(det.detect(im), want)
     det.hd.close()
+
+
+def test_pipelined_submit_wait_equals_synchronous_batches(det_mod, oracle):
+    """pbd_detect_batch_submit / _wait with two batches in flight: every batch's records equal those of the synchronous
+    pbd_detect_batch on the same frames (and, for one frame, the oracle); call-order violations are status codes."""
+    from partsbaseddetector_amd._lib import PbdError
+    model = M.synthetic_tiny_model(thresh=0.5)
+    flat = model.flatten()
+    det = det_mod.PartsBasedDetector(device=0, max_batch=4)
+    det.distributeModel(model)
+    batches = [[synth.synthetic_frame(100 + 10 * b + i, 120, 150, 3) for i in range(4 if b != 2 else 3)] for b in range(5)]
+    want = [[(c.frame, c.level, c.component, c.root, c.score(), c.parts.tobytes()) for c in det.detect_batch(fr)] for fr in batches]
+    with pytest.raises(PbdError) as e:
+        det.wait_batch()                                   # nothing in flight
+    assert e.value.code == -5
+    got = []
+    det.submit_batch(batches[0])
+    for b in range(1, len(batches)):
+        det.submit_batch(batches[b])                       # two in flight
+        if b == 1:
+            with pytest.raises(PbdError) as e:
+                det.submit_batch(batches[0])               # a third is refused
+            assert e.value.code == -5
+            with pytest.raises(PbdError) as e:
+                det.detect(batches[0][0])                  # and so is a synchronous call
+            assert e.value.code == -5
+        got.append(det.wait_batch())
+    got.append(det.wait_batch())
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert [(c.frame, c.level, c.component, c.root, c.score(), c.parts.tobytes()) for c in g] == w
+    _compare_candidates([c for c in got[3] if c.frame == 2], oracle.detect(flat, batches[3][2]))
+    assert len(det.detect(batches[0][0])) > 0              # synchronous calls work again
+    det.hd.close()

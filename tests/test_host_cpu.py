@@ -124,3 +124,44 @@ def test_sort_and_nms():
     kept = list(cands)
     Candidate.nonMaximaSuppression((100, 100), kept, 0.1)       # callers' default (cells/detect.cpp:124, ros/Node.cpp:196)
     assert [x.score() for x in kept] == [9.0, 3.0, 2.5, 1.0]    # e: 25/400 = 0.0625 <= 0.1 kept; b: 0.9 suppressed
+
+
+def test_nms_against_a_painted_pixel_set():
+    """Independent formulation of include/Candidate.hpp:277-304 (not the implementation under test run twice): the
+    canvas is a Python set of painted (x, y) pixels; a candidate's box is the set of image pixels inside the hull of
+    its non-empty part rectangles.  Random candidates incl. boxes partly / entirely outside the image, zero-area parts
+    and duplicates; several overlap thresholds."""
+    from partsbaseddetector_amd.detector import Candidate
+    rng = np.random.default_rng(7)
+    rows, cols = 60, 80
+    for trial in range(30):
+        cands = []
+        for i in range(int(rng.integers(1, 25))):
+            nparts = int(rng.integers(1, 5))
+            parts = []
+            for _ in range(nparts):
+                x, y = int(rng.integers(-30, cols + 10)), int(rng.integers(-30, rows + 10))
+                w, h = int(rng.integers(0, 40)), int(rng.integers(0, 40))        # zero width / height happens
+                parts.append((x, y, w, h))
+            if parts[0][2] == 0 or parts[0][3] == 0:
+                parts[0] = (parts[0][0], parts[0][1], max(parts[0][2], 1), max(parts[0][3], 1))
+            cands.append(_cand(parts, float(rng.standard_normal())))
+        if trial % 3 == 0 and cands:
+            cands.append(_cand([tuple(int(v) for v in p) for p in cands[0].parts], cands[0].score() - 1e-3))   # a duplicate box
+        Candidate.sort(cands)
+        assert all(a.score() >= b.score() for a, b in zip(cands, cands[1:]))
+        for overlap in (0.0, 0.1, 0.5):
+            painted, want = set(), []
+            for c in cands:
+                px = set()
+                live = [(x, y, w, h) for x, y, w, h in (tuple(int(v) for v in p) for p in c.parts) if w > 0 and h > 0]
+                x1 = min(p[0] for p in live); y1 = min(p[1] for p in live)
+                x2 = max(p[0] + p[2] for p in live); y2 = max(p[1] + p[3] for p in live)
+                box = {(x, y) for x in range(max(x1, 0), min(x2, cols)) for y in range(max(y1, 0), min(y2, rows))}
+                if box and len(box & painted) / len(box) > overlap:
+                    continue                         # suppressed
+                painted |= box                       # an empty box (outside the image) is kept and paints nothing
+                want.append(id(c))
+            kept = list(cands)
+            Candidate.nonMaximaSuppression((rows, cols), kept, overlap)
+            assert [id(c) for c in kept] == want, (trial, overlap)
