@@ -286,10 +286,18 @@ def test_person_model_full_size_frames(det_mod, oracle, shape, seed):
     det.hd.close()
 
 
-def test_face_config_plumbing(det_mod, oracle):
-    """BASELINE configs[0]: face-like model (many parts, 1 mixture, several components sharing filters),
-    320x240 frame, interval 5."""
-    model = M.synthetic_face_model(thresh=6.0, nparts=20, ncomponents=3, interval=5)
+def test_face_config_plumbing(det_mod, oracle, tmp_path):
+    """BASELINE configs[0]: a `.by_parts` configuration (pipeline1.parameters.extra.model_file, as
+    conf/config_face.by_parts:31) names an XML model that does not ship -> the synthetic face-like stand-in (many parts,
+    1 mixture, several components sharing filters), written to and re-read from the XML flavour of the model format,
+    one 320x240 frame, interval 5."""
+    from partsbaseddetector_amd import config as CFG, filestorage as FS
+    (tmp_path / "config_face.by_parts").write_text(
+        "pipeline1:\n  type: PartsBasedDetector\n  parameters:\n    extra:\n      model_file: \"/nowhere/Face_68parts.xml\"\n      use_cuda: false\n")
+    cfg = CFG.load_by_parts(str(tmp_path / "config_face.by_parts"))[0]
+    stand_in = CFG.load_model(cfg, stand_in=M.synthetic_face_model(thresh=6.0, nparts=20, ncomponents=3, interval=5))
+    FS.serialize_xml(stand_in, str(tmp_path / "Face_68parts.xml"))
+    model = CFG.load_model(cfg, search_dirs=[str(tmp_path)])           # now found next to the config: the XML reader's output
     flat = model.flatten()
     det = det_mod.PartsBasedDetector(device=0)
     det.distributeModel(model)

@@ -165,3 +165,64 @@ def test_nms_against_a_painted_pixel_set():
             kept = list(cands)
             Candidate.nonMaximaSuppression((rows, cols), kept, overlap)
             assert [id(c) for c in kept] == want, (trial, overlap)
+
+
+def test_by_parts_config(tmp_path):
+    """BASELINE configs[0] plumbing: a `.by_parts` pipeline description -> pipeline1.parameters.extra.model_file
+    (reference conf/config_face.by_parts, cells/detect.cpp:115-126) -> model."""
+    from partsbaseddetector_amd import config as CFG
+    model = M.synthetic_face_model(thresh=1.5, nparts=5, ncomponents=2)
+    FS.serialize_xml(model, str(tmp_path / "Face_5parts.xml"))
+    text = """
+source1:
+  type: RosKinect
+  module: object_recognition_ros.io
+sink1:
+  type: Publisher
+  module: 'object_recognition_by_parts'
+pipeline1:
+  type: PartsBasedDetector
+  module: 'object_recognition_by_parts'
+  inputs: [source1]
+  outputs: [sink1]
+  parameters:
+    object_ids: ['abc']
+    visualize: true
+    extra:
+        model_file: "/somewhere/else/models/Face_5parts.xml"
+        use_cuda: false
+"""
+    path = tmp_path / "config_face.by_parts"
+    path.write_text(text)
+    cfgs = CFG.load_by_parts(str(path))
+    assert len(cfgs) == 1
+    c = cfgs[0]
+    assert c.pipeline == "pipeline1" and c.model_file.endswith("Face_5parts.xml") and c.visualize and not c.use_cuda
+    assert c.max_overlap == pytest.approx(0.1)                                   # cells/detect.cpp:124 default
+    with pytest.raises(FileNotFoundError):
+        CFG.load_model(c)                                                        # the authors' absolute path
+    _same_model(model, CFG.load_model(c, search_dirs=[str(tmp_path)]))           # same file name next to the config
+    stand_in = M.synthetic_face_model()
+    assert CFG.load_model(c, stand_in=stand_in) is stand_in                      # no file: synthetic stand-in
+    (tmp_path / "bad.by_parts").write_text("pipeline1:\n  type: PartsBasedDetector\n  parameters: {}\n")
+    with pytest.raises(ValueError):
+        CFG.load_by_parts(str(tmp_path / "bad.by_parts"))
+
+
+@pytest.mark.parametrize("which", ["tiny", "face"])
+def test_xml_writer_roundtrip(tmp_path, which):
+    model = M.synthetic_tiny_model(thresh=-0.25) if which == "tiny" else M.synthetic_face_model(thresh=1.5, nparts=7, ncomponents=2)
+    path = str(tmp_path / "model.xml")
+    assert FS.serialize_xml(model, path)
+    _same_model(model, FS.deserialize(path))
+
+
+def test_validate_raises_value_error():
+    m = M.synthetic_tiny_model()
+    m.parentid[0][1] = 2                        # parent after child
+    with pytest.raises(ValueError):
+        m.validate()
+    m = M.synthetic_tiny_model()
+    m.filterid[0][2][0] = 99
+    with pytest.raises(ValueError):
+        m.flatten()

@@ -58,6 +58,51 @@ def test_demo_fails_loudly_without_gpu(demo, tmp_path):
     assert r.returncode != 0 and "Image not found" in r.stderr
 
 
+def _dump_digest(model):
+    """what `pbd_demo --dump-model` prints for `model` (every field FileStorageModel::deserialize fills)"""
+    out = [f"name {model.name}", f"interval {model.interval}", f"thresh {float(np.float32(model.thresh)):.9g}", f"sbin {model.sbin}",
+           f"norient {model.norient}", f"flen {model.flen}"]
+    for i, f in enumerate(model.filtersw):
+        f = np.asarray(f, np.float64)
+        out.append(f"filter {i} {f.shape[0]} {f.shape[1]} " + " ".join("%.17g" % v for v in f.ravel()))
+    out.append(("biasw " + " ".join("%.9g" % float(np.float32(b)) for b in model.biasw)).rstrip())
+    out.append(("anchors " + " ".join(f"{a[0]},{a[1]}" for a in model.anchors)).rstrip())
+    for d, w in enumerate(model.defw):
+        out.append(f"def {d} " + " ".join("%.9g" % float(np.float32(v)) for v in w))
+    for c in range(model.ncomponents()):
+        for p in range(model.nparts(c)):
+            line = f"part {c} {p} parent {model.parentid[c][p]} filterid " + " ".join(str(v) for v in model.filterid[c][p])
+            line += " biasid" + "".join(f" {v}" for v in model.biasid[c][p]) + " defid" + "".join(f" {v}" for v in model.defid[c][p])
+            out.append(line)
+    return out
+
+
+@pytest.mark.parametrize("which", ["tiny", "face", "person"])
+def test_cpp_reader_yaml_and_xml(demo, tmp_path, which):
+    """pbdhost::FileStorageModel::deserialize (src/FileStorageModel.cpp:96-159) on the YAML and on the XML flavour of
+    the same model (the reference's configs name XML models: conf/config_person.by_parts:30): both must hand back
+    every field exactly -- checked through `pbd_demo <model> --dump-model`, which needs no GPU."""
+    model = {"tiny": M.synthetic_tiny_model(thresh=-0.25), "face": M.synthetic_face_model(thresh=1.5, nparts=7, ncomponents=2),
+             "person": M.synthetic_person_model()}[which]
+    want = _dump_digest(model)
+    for ext, writer in (("yml", FS.serialize), ("xml", FS.serialize_xml)):
+        path = str(tmp_path / f"model.{ext}")
+        writer(model, path)
+        r = subprocess.run([demo, path, "--dump-model"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = [ln.rstrip() for ln in r.stdout.strip().splitlines()]
+        assert len(got) == len(want), (ext, len(got), len(want))
+        for a, b in zip(got, want):
+            assert a.split() == b.split(), (ext, a[:120], b[:120])
+
+
+def test_cpp_reader_rejects_malformed_xml(demo, tmp_path):
+    bad = tmp_path / "bad.xml"
+    bad.write_text('<?xml version="1.0"?>\n<opencv_storage>\n<interval>5</interval>\n<thresh>0.</thresh>')   # unterminated
+    r = subprocess.run([demo, str(bad), "--dump-model"], capture_output=True, text=True)
+    assert r.returncode != 0 and "model file" in r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags,dtype", [([], np.float32), (["--staged"], np.float32), (["--double"], np.float64),
                                          (["--double", "--staged"], np.float64)])
