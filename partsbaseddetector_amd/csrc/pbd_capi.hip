@@ -129,9 +129,11 @@ struct Group {   // DT jobs of the parts of one tree depth + combine jobs of the
     std::vector<DtJob> jobs;
     std::vector<ChildDesc> childs;
     std::vector<CombineJob> cjobs;
+    std::vector<SeqCombineJob> sjobs;     // sequential schedule (shared filter ids): replaces childs / cjobs
     DevTable<DtJob> d_jobs;
     DevTable<ChildDesc> d_childs;
     DevTable<CombineJob> d_cjobs;
+    DevTable<SeqCombineJob> d_sjobs;
 };
 
 struct Prof {
@@ -187,10 +189,18 @@ struct pbd_handle {
     int JGmax = 0;
     int max_mix = 1;                 // largest number of mixtures of any part
     bool filters_set = false;
+    bool seq_mode = false;           // a filter id occurs twice inside a component: sequential schedule, accumulators keyed by filter id
     bool bank_matches_model = true;  // false after a setFilters() whose bank no longer covers the model's filter ids
 
     // device model tables
-    DevBuf d_wts;                    // real-typed weights
+    // convolution bank: the filters grouped by size (one class in every known model; the reference builds one engine
+    // per filter and so takes any mix: src/SpatialConvolutionEngine.cpp:141-158)
+    struct ConvClass {
+        int K = 0, nf = 0, Fpad = 0;
+        DevBuf wts;                  // real-typed weights of the class
+        DevTable<int> fmap;          // class-local index -> filter id (empty when the class is the whole bank in order)
+    };
+    std::vector<ConvClass> conv_classes;
     DevBuf d_wrec;                   // bf16 hi/lo weight records of the matrix-core path
     DevTable<float> d_biasw;
     DevTable<int> d_walk_off;
@@ -509,26 +519,42 @@ template <typename R>
 int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize)
 {
     if (nfilters <= 0) return fail(h, PBD_ERR_INVALID, "no filters");
-    const int K = ksize[0];
     for (int f = 0; f < nfilters; ++f)
-        if (ksize[f] != K) return fail(h, PBD_ERR_UNSUPPORTED, "filters of different sizes (%d vs %d) are not supported", ksize[f], K);
-    if (K < 1 || K > 7) return fail(h, PBD_ERR_UNSUPPORTED, "filter size %d not supported (1..7)", K);
-    const int Fpad = (nfilters + kConvQ - 1) / kConvQ * kConvQ;
-    // device layout: float 5x5 kernel [group][channel][tap][8] (800 contiguous bytes per (group, channel));
-    // generic kernel (other sizes, T=double) [channel][tap][Fpad]
-    const bool fast = (sizeof(R) == 4 && K == 5);
-    std::vector<R> w((size_t)32 * K * K * Fpad, (R)0);
-    for (int f = 0; f < nfilters; ++f) {
-        const R *src = static_cast<const R *>(filters[f]);
-        for (int t = 0; t < K * K; ++t)
-            for (int c = 0; c < 32; ++c) {
-                const R v = src[(size_t)t * 32 + c];
-                if (fast) w[(((size_t)(f / kConvQ) * 32 + c) * K * K + t) * kConvQ + (f % kConvQ)] = v;
-                else w[((size_t)c * K * K + t) * Fpad + f] = v;
-            }
+        if (ksize[f] < 1 || ksize[f] > 7) return fail(h, PBD_ERR_UNSUPPORTED, "filter %d: size %d not supported (1..7)", f, ksize[f]);
+    // size classes in order of first appearance
+    std::vector<int> sizes;
+    for (int f = 0; f < nfilters; ++f)
+        if (std::find(sizes.begin(), sizes.end(), ksize[f]) == sizes.end()) sizes.push_back(ksize[f]);
+    const int K = ksize[0];
+    const bool fast = (sizeof(R) == 4 && K == 5 && sizes.size() == 1);
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); }
+    h->conv_classes.assign(sizes.size(), pbd_handle::ConvClass{});
+    for (size_t ci = 0; ci < sizes.size(); ++ci) {
+        pbd_handle::ConvClass &C = h->conv_classes[ci];
+        C.K = sizes[ci];
+        std::vector<int> ids;
+        for (int f = 0; f < nfilters; ++f) if (ksize[f] == C.K) ids.push_back(f);
+        C.nf = (int)ids.size();
+        C.Fpad = (C.nf + kConvQ - 1) / kConvQ * kConvQ;
+        // device layout: float 5x5 kernel [group][channel][tap][8] (800 contiguous bytes per (group, channel));
+        // generic kernel (other sizes, T=double) [channel][tap][Fpad]
+        const bool fast5 = (sizeof(R) == 4 && C.K == 5);
+        const int KK = C.K * C.K;
+        std::vector<R> w((size_t)32 * KK * C.Fpad, (R)0);
+        for (int fl = 0; fl < C.nf; ++fl) {
+            const R *src = static_cast<const R *>(filters[ids[fl]]);
+            for (int t = 0; t < KK; ++t)
+                for (int c = 0; c < 32; ++c) {
+                    const R v = src[(size_t)t * 32 + c];
+                    if (fast5) w[(((size_t)(fl / kConvQ) * 32 + c) * KK + t) * kConvQ + (fl % kConvQ)] = v;
+                    else w[((size_t)c * KK + t) * C.Fpad + fl] = v;
+                }
+        }
+        HIPCHK(h, C.wts.ensure(w.size() * sizeof(R)));
+        HIPCHK(h, hipMemcpy(C.wts.p, w.data(), w.size() * sizeof(R), hipMemcpyHostToDevice));
+        if (sizes.size() > 1) HIPCHK(h, C.fmap.upload(ids));
     }
-    HIPCHK(h, h->d_wts.ensure(w.size() * sizeof(R)));
-    HIPCHK(h, hipMemcpy(h->d_wts.p, w.data(), w.size() * sizeof(R), hipMemcpyHostToDevice));
+    const int Fpad = (nfilters + kConvQ - 1) / kConvQ * kConvQ;
     if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16) {
         if (!fast) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA / PBD_CONV_MFMA_F16 need 5x5 filters and PBD_REAL_F32");
         const bool f16 = h->cfg.conv_mode == PBD_CONV_MFMA_F16;
@@ -658,7 +684,7 @@ int build_model(pbd_handle *h, const pbd_model *m)
             for (int mm = 0; mm < K; ++mm) {
                 const int f = h->filterid[h->mix_offset[gp] + mm];
                 if (f < 0 || f >= h->F) return fail(h, PBD_ERR_INVALID, "filter id %d out of range", f);
-                if (!seen.insert(f).second) return fail(h, PBD_ERR_UNSUPPORTED, "filter %d used twice in component %d", f, c);
+                if (!seen.insert(f).second) h->seq_mode = true;   // accumulators keyed by filter id interact: see below
             }
             h->ptr_slot[gp] = NS;
             if (p > 0) {
@@ -691,11 +717,54 @@ int build_model(pbd_handle *h, const pbd_model *m)
         for (int p = np - 1; p > 0; --p) children[p0 + h->parentid[p0 + p]].push_back(p0 + p);
     }
 
-    // depth groups, deepest first: DT jobs of the parts at depth `dep`, combine jobs of their parents
-    h->NM = totmix;
     h->groups.clear();
     h->JGmax = 0;
-    for (int dep = maxdepth; dep >= 1; --dep) {
+    h->NM = totmix;
+    auto dt_job = [&](int gm, bool from_acc, int plane) {
+        DtJob j{};
+        j.from_acc = from_acc ? 1 : 0;
+        j.plane = plane;
+        const int d = h->defid[gm];
+        const float *w = &h->defw[(size_t)d * 4];
+        j.ax = (double)(-w[0]); j.bx = (double)(-w[1]); j.ay = (double)(-w[2]); j.by = (double)(-w[3]);
+        j.osx = h->anchors[(size_t)d * 2]; j.osy = h->anchors[(size_t)d * 2 + 1];
+        return j;
+    };
+    std::vector<std::vector<char>> touched(h->NC, std::vector<char>(h->F, 0));   // sequential schedule: accumulator (c, f) exists
+    if (h->seq_mode) {
+        // The reference's own order (src/DynamicProgram.cpp:95): parts nparts-1 .. 1, one step per part; the
+        // accumulated scores live in planes keyed by (component, filter id) as its `ncscores` (:93,115-119,154-156).
+        // Step s takes part np-1-s of every component (components are independent).
+        h->NM = h->NC * h->F;
+        for (int sidx = 0; sidx + 1 < h->max_parts; ++sidx) {
+            Group g;
+            for (int c = 0; c < h->NC; ++c) {
+                const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
+                const int p = np - 1 - sidx;
+                if (p < 1) continue;
+                const int gp = p0 + p, gpar = p0 + h->parentid[gp];
+                const int K = h->mix_offset[gp + 1] - h->mix_offset[gp], L = h->mix_offset[gpar + 1] - h->mix_offset[gpar];
+                SeqCombineJob sj{};
+                sj.job_begin = (int)g.jobs.size(); sj.nmix = K; sj.slot = h->ptr_slot[gp]; sj.npar = L;
+                for (int mm = 0; mm < K; ++mm) {
+                    const int gm = h->mix_offset[gp] + mm, f = h->filterid[gm];
+                    g.jobs.push_back(dt_job(gm, touched[c][f] != 0, touched[c][f] ? c * h->F + f : f));   // score_in, :115-119
+                    sj.bias_off[mm] = h->biasid[gm];
+                }
+                for (int pm = 0; pm < L; ++pm) {
+                    const int fp = h->filterid[h->mix_offset[gpar] + pm];
+                    sj.target[pm] = c * h->F + fp; sj.filter[pm] = fp;
+                    sj.init[pm] = touched[c][fp] ? 0 : 1;
+                    touched[c][fp] = 1;
+                }
+                g.sjobs.push_back(sj);
+            }
+            h->JGmax = std::max(h->JGmax, (int)g.jobs.size());
+            h->groups.push_back(std::move(g));
+        }
+    }
+    // depth groups, deepest first: DT jobs of the parts at depth `dep`, combine jobs of their parents
+    for (int dep = h->seq_mode ? 0 : maxdepth; dep >= 1; --dep) {
         Group g;
         std::vector<int> job_begin_of(totparts, -1);
         for (int c = 0; c < h->NC; ++c) {
@@ -707,14 +776,7 @@ int build_model(pbd_handle *h, const pbd_model *m)
                 job_begin_of[gp] = (int)g.jobs.size();
                 for (int mm = 0; mm < K; ++mm) {
                     const int gm = h->mix_offset[gp] + mm;
-                    DtJob j{};
-                    j.from_acc = children[gp].empty() ? 0 : 1;
-                    j.plane = j.from_acc ? gm : h->filterid[gm];
-                    const int d = h->defid[gm];
-                    const float *w = &h->defw[(size_t)d * 4];
-                    j.ax = (double)(-w[0]); j.bx = (double)(-w[1]); j.ay = (double)(-w[2]); j.by = (double)(-w[3]);
-                    j.osx = h->anchors[(size_t)d * 2]; j.osy = h->anchors[(size_t)d * 2 + 1];
-                    g.jobs.push_back(j);
+                    g.jobs.push_back(dt_job(gm, !children[gp].empty(), children[gp].empty() ? h->filterid[gm] : gm));
                 }
             }
             // parents at depth dep-1 whose children (all at depth dep) were just listed
@@ -745,6 +807,7 @@ int build_model(pbd_handle *h, const pbd_model *m)
         HIPCHK(h, g.d_jobs.upload(g.jobs));
         HIPCHK(h, g.d_childs.upload(g.childs));
         HIPCHK(h, g.d_cjobs.upload(g.cjobs));
+        HIPCHK(h, g.d_sjobs.upload(g.sjobs));
     }
     h->rjobs.assign(h->NC, RootJob{});
     h->walk.clear(); h->walk_off.assign(h->NC + 1, 0);
@@ -752,8 +815,13 @@ int build_model(pbd_handle *h, const pbd_model *m)
         const int p0 = h->part_offset[c], np = h->part_offset[c + 1] - p0;
         RootJob &r = h->rjobs[c];
         r.nmix = h->mix_offset[p0 + 1] - h->mix_offset[p0];
-        r.from_acc = children[p0].empty() ? 0 : 1;
-        for (int mm = 0; mm < r.nmix; ++mm) r.plane[mm] = r.from_acc ? h->mix_offset[p0] + mm : h->filterid[h->mix_offset[p0] + mm];
+        r.from_acc = 0;
+        for (int mm = 0; mm < r.nmix; ++mm) {
+            const int f = h->filterid[h->mix_offset[p0] + mm];
+            const bool acc = h->seq_mode ? touched[c][f] != 0 : !children[p0].empty();
+            if (acc) r.from_acc |= 1 << mm;
+            r.plane[mm] = !acc ? f : h->seq_mode ? c * h->F + f : h->mix_offset[p0] + mm;
+        }
         r.bias = h->biasw[h->biasid[h->mix_offset[p0]]];
         h->walk_off[c] = (int)h->walk.size();
         for (int p = 0; p < np; ++p) {
@@ -833,18 +901,21 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     cp.lv = P.d_lv.d; cp.tiles = P.d_tiles.d; cp.ntiles = P.ntiles;
     cp.shaped = P.d_shaped.d;
     for (int k = 0; k < 3; ++k) cp.nshaped[k] = P.nshaped[k];
-    cp.F = h->F; cp.Fpad = h->Fpad; cp.ksize = h->ksize; cp.frame0 = f0;
-    const int ngroups = h->Fpad / kConvQ;
-    // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
-    const long long wgs = (long long)P.ntiles * nb;
-    cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
+    cp.F = h->F; cp.frame0 = f0;
     cp.cell_per_frame = P.cell_per_frame;
-    cp.feat = h->feat.p; cp.wts = h->d_wts.p; cp.resp = h->resp.p;
+    cp.feat = h->feat.p; cp.resp = h->resp.p;
     cp.fma = h->cfg.conv_mode == PBD_CONV_FMA;
     ProfScope ps(h, PBD_K_CONV, st);
-    if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16)
-        launch_conv_mfma(cp, h->d_wrec.p, h->cfg.conv_mode == PBD_CONV_MFMA_F16, nb, st);
-    else launch_conv(cp, nb, h->f64, st);
+    for (const pbd_handle::ConvClass &C : h->conv_classes) {     // one launch per filter size (one class in every known model)
+        cp.nf = C.nf; cp.Fpad = C.Fpad; cp.ksize = C.K; cp.wts = C.wts.p; cp.fmap = C.fmap.d;
+        const int ngroups = C.Fpad / kConvQ;
+        // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
+        const long long wgs = (long long)P.ntiles * nb;
+        cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
+        if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16)
+            launch_conv_mfma(cp, h->d_wrec.p, h->cfg.conv_mode == PBD_CONV_MFMA_F16, nb, st);
+        else launch_conv(cp, nb, h->f64, st);
+    }
 }
 
 // frames per DP chunk so that the chunk scratch stays within the budget
@@ -904,7 +975,12 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
         dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d; dp.childs = g.d_childs.d;
         { ProfScope ps(h, PBD_K_DT_ROWS, st); launch_dt_rows(dp, nb, h->f64, st); }
         { ProfScope ps(h, PBD_K_DT_COLS, st); launch_dt_cols(dp, nb, h->f64, st); }
-        { ProfScope ps(h, PBD_K_DP_COMBINE, st); launch_dp_combine(dp, (int)g.cjobs.size(), nb, h->f64, st); }
+        dp.sjobs = g.d_sjobs.d;
+        {
+            ProfScope ps(h, PBD_K_DP_COMBINE, st);
+            if (h->seq_mode) launch_dp_combine_seq(dp, (int)g.sjobs.size(), nb, h->f64, st);
+            else launch_dp_combine(dp, (int)g.cjobs.size(), nb, h->f64, st);
+        }
     }
     { ProfScope ps(h, PBD_K_DP_ROOT, st); launch_dp_root(dp, nb, h->f64, st); }
 }
@@ -1195,9 +1271,10 @@ void pbd_destroy(pbd_handle *h)
                       &h->rooti, &h->tmp, &h->dt, &h->IxT, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();
-    h->d_wts.release(); h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_walk_off.release();
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); }
+    h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_walk_off.release();
     h->d_rjobs.release(); h->d_walk.release();
-    for (auto &g : h->groups) { g.d_jobs.release(); g.d_childs.release(); g.d_cjobs.release(); }
+    for (auto &g : h->groups) { g.d_jobs.release(); g.d_childs.release(); g.d_cjobs.release(); g.d_sjobs.release(); }
     h->plans.clear();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     } catch (...) {

@@ -67,9 +67,24 @@ struct CombineJob {
 
 struct RootJob {              // one per component
     int nmix;
-    int plane[8];             // filter id or global mixture index per root mixture
-    int from_acc;
+    int plane[8];             // response plane (filter id) or accumulated-score plane per root mixture
+    int from_acc;             // bit mm set: plane[mm] is an accumulated-score plane
     float bias;
+};
+
+// Sequential schedule (a filter id used more than once inside a component): the reference keys the accumulated
+// scores by FILTER id (src/DynamicProgram.cpp:93,115-119,154-156), so parts sharing a filter see each other's
+// contributions in processing order (parts nparts-1 .. 1).  One step = one part per component, and this job is the
+// part's contribution to its parent's accumulators, applied in place in parent-mixture order.
+struct SeqCombineJob {
+    int job_begin;            // first DtJob of the part within the step
+    int nmix;                 // the part's mixtures K
+    int slot;                 // back-pointer slot of (part, parent mixture 0)
+    int bias_off[8];          // biasid[part][mm]
+    int npar;                 // parent mixtures L
+    int target[8];            // accumulated-score plane (component * F + filter id of (parent, pm))
+    int filter[8];            // filter id of (parent, pm): the plane the accumulator starts from
+    int init[8];              // 1: the accumulator has not been touched yet -> start from the raw response (:155)
 };
 
 struct PartWalk {             // argmin tree walk, one per part of a component
@@ -116,7 +131,9 @@ struct ConvParams {
     int ntiles;
     const ConvTile *shaped;       // mixed-shape tiling of the exact 5x5 kernel: 32x8 tiles, then 16x16, then 8x32
     int nshaped[3];
-    int F, Fpad, ksize;
+    int F;                        // response planes per cell block (all filters of the bank)
+    int nf, Fpad, ksize;          // this launch: filters of one size class, padded to kConvQ, their size
+    const int *fmap;              // class-local filter index -> response plane (NULL: identity, the single-class case)
     int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
     int frame0;
     long long cell_per_frame;
@@ -150,6 +167,7 @@ struct DpParams {
     const DtJob *jobs;
     const ChildDesc *childs;
     const CombineJob *cjobs;
+    const SeqCombineJob *sjobs;   // sequential schedule only
     const float *biasw;
     const int *row2level; const int *rowoff;   // flat row -> level, level -> first flat row
     const int *col2level; const int *coloff;
@@ -189,6 +207,7 @@ constexpr int kMfmaFilterBlock = 160, kMfmaRecBytes = 144, kMfmaRecBytesF16 = 80
 void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s);
 void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s);
 void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hipStream_t s);
+void launch_dp_combine_seq(const DpParams &p, int nsjobs, int nframes, bool f64, hipStream_t s);
 void launch_dp_root(const DpParams &p, int nframes, bool f64, hipStream_t s);
 void launch_argmin_find(const ArgminParams &p, bool f64, hipStream_t s);
 void launch_argmin_walk(const ArgminParams &p, int ncand, bool f64, hipStream_t s);

@@ -223,7 +223,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #undef PBD_PIN
         // a full group (all but possibly the last) stores without per-filter branches: one block of 8
         // independent stores per row
-        if (g * Q + Q <= p.F) {
+        if (g * Q + Q <= p.nf && p.fmap == nullptr) {
             float *rg = resp + (size_t)(g * Q) * HW;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
@@ -239,7 +239,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const int f = g * Q + q;
-                        if (f < p.F) resp[(size_t)f * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
+                        if (f < p.nf) resp[(size_t)(p.fmap ? p.fmap[f] : f) * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
                     }
                 }
             }
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int f = g * Q + q;
-                if (f < p.F) resp[(size_t)f * HW] = r[q];
+                if (f < p.nf) resp[(size_t)(p.fmap ? p.fmap[f] : f) * HW] = r[q];
             }
         }
     }
@@ -360,7 +360,7 @@ static void launch_shapes(const ConvParams &p, int gy, int nframes, hipStream_t 
 
 void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s)
 {
-    if (p.ntiles == 0 || p.F == 0) return;
+    if (p.ntiles == 0 || p.nf == 0) return;
     const int ngroups = p.Fpad / kConvQ;
     const int gy = (ngroups + p.groups_per_block - 1) / p.groups_per_block;
     dim3 grid(p.ntiles, gy, nframes);

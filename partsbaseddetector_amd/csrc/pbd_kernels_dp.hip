@@ -483,6 +483,65 @@ void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hip
 #undef PBD_COMBINE
 }
 
+// ---- combine, sequential schedule: thread = one cell, block.y = one (component, part) of the step -------------
+// For every parent mixture pm, in order: weighted[mm] = score_dt[mm] + bias(mm)[pm]; reduceMax; pointer pick with the
+// Iy composition; then `parent.score[pm] += max` IN PLACE on the accumulator keyed by the parent mixture's filter id,
+// which starts as a copy of the raw response the first time it is touched (src/DynamicProgram.cpp:134-156).
+template <typename R>
+__global__ __launch_bounds__(256) void k_dp_combine_seq(DpParams p)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.cell_per_frame) return;
+    const int fl = blockIdx.z, frame = p.frame0 + fl;
+    const SeqCombineJob sj = p.sjobs[blockIdx.y];
+    int lo = 0, hi = p.nlevels;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (p.lv[mid].cell_off <= idx) lo = mid; else hi = mid; }
+    const LevelDesc d = p.lv[lo];
+    const int W = d.cols;
+    const int local = (int)(idx - d.cell_off);
+    const size_t HW = (size_t)d.rows * W;
+    const int rowbase = (local / W) * W;
+    const size_t gbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)sj.job_begin * HW;
+    const size_t pbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + local;
+    const R *respp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + local;
+    R *accp = static_cast<R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM + local;
+    const R *dtp = static_cast<const R *>(p.dt) + gbase + local;
+    R dtv[kMaxMix];
+    int ixv[kMaxMix];
+    for (int mm = 0; mm < sj.nmix; ++mm) {
+        dtv[mm] = dtp[(size_t)mm * HW];
+        ixv[mm] = p.IxRaw[gbase + (size_t)mm * HW + local];
+    }
+    for (int pm = 0; pm < sj.npar; ++pm) {
+        R best;
+        int bi = 0;
+        if (sj.nmix == 1) {
+            best = dtv[0] + (R)p.biasw[sj.bias_off[0] + pm];
+        } else {
+            best = -RealLimits<R>::inf();
+            for (int mm = 0; mm < sj.nmix; ++mm) {
+                const R wv = dtv[mm] + (R)p.biasw[sj.bias_off[mm] + pm];
+                if (wv > best) { bi = mm; best = wv; }
+            }
+        }
+        const int ix = ixv[bi];
+        const int iy = p.IyRaw[gbase + (size_t)bi * HW + rowbase + ix];
+        const size_t o = pbase + (size_t)(sj.slot + pm) * HW;
+        p.Ix[o] = (int16_t)ix; p.Iy[o] = (int16_t)iy; p.Ik[o] = (uint8_t)bi;
+        R *t = accp + (size_t)sj.target[pm] * HW;
+        const R base = sj.init[pm] ? respp[(size_t)sj.filter[pm] * HW] : *t;
+        *t = base + best;
+    }
+}
+
+void launch_dp_combine_seq(const DpParams &p, int nsjobs, int nframes, bool f64, hipStream_t s)
+{
+    if (nsjobs == 0 || p.cell_per_frame == 0) return;
+    dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), nsjobs, nframes);
+    if (f64) hipLaunchKernelGGL(k_dp_combine_seq<double>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_dp_combine_seq<float>, grid, dim3(256), 0, s, p);
+}
+
 // ---- root: rootv = max over root mixtures of (accumulated score + bias) ----------------------------
 template <typename R>
 __global__ __launch_bounds__(256) void k_dp_root(DpParams p)
@@ -496,16 +555,16 @@ __global__ __launch_bounds__(256) void k_dp_root(DpParams p)
     const LevelDesc d = p.lv[lo];
     const int local = (int)(idx - d.cell_off);
     const size_t HW = (size_t)d.rows * d.cols;
-    const R *src = rj.from_acc ? static_cast<const R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM
-                               : static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
+    const R *accp = static_cast<const R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM;
+    const R *respp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
     R best;
     int bi = 0;
     if (rj.nmix == 1) {
-        best = src[(size_t)rj.plane[0] * HW + local] + (R)rj.bias;
+        best = ((rj.from_acc & 1) ? accp : respp)[(size_t)rj.plane[0] * HW + local] + (R)rj.bias;
     } else {
         best = -RealLimits<R>::inf();
         for (int mm = 0; mm < rj.nmix; ++mm) {
-            const R wv = src[(size_t)rj.plane[mm] * HW + local] + (R)rj.bias;
+            const R wv = (((rj.from_acc >> mm) & 1) ? accp : respp)[(size_t)rj.plane[mm] * HW + local] + (R)rj.bias;
             if (wv > best) { bi = mm; best = wv; }
         }
     }

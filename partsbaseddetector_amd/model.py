@@ -142,7 +142,7 @@ class FlatModel:
         self.nslots = total
 
 
-def synthetic_model(seed: int = 26, pa=None, nmix: int = 6, ncomponents: int = 1, ksize: int = 5,
+def synthetic_model(seed: int = 26, pa=None, nmix: int = 6, ncomponents: int = 1, ksize=5,
                     sbin: int = 4, interval: int = 10, thresh: float = 0.0, linear_def: bool = False,
                     anchor_range: int = 4, filter_sigma: float = 0.05, bias_sigma: float = 0.1,
                     share_filters: bool = False, name: str = "synthetic") -> Model:
@@ -182,11 +182,13 @@ def synthetic_model(seed: int = 26, pa=None, nmix: int = 6, ncomponents: int = 1
             else:
                 fid = []
                 for _ in range(K):
-                    w = draw(ksize * ksize * flen) * filter_sigma
+                    # ksize may be a list: filter sizes then cycle through it (a model with filters of several sizes)
+                    ks = ksize[len(m.filtersw) % len(ksize)] if isinstance(ksize, (list, tuple)) else ksize
+                    w = draw(ks * ks * flen) * filter_sigma
                     # a few exact zeros exercise the skipped-tap rule (src/filter.cpp:3818-3856)
                     w[draw_int(8, 0, w.size - 1)] = 0.0
                     fid.append(len(m.filtersw))
-                    m.filtersw.append(w.reshape(ksize, ksize * flen))
+                    m.filtersw.append(w.reshape(ks, ks * flen))
             fid_c.append(fid)
             # bias
             if parent < 0:

@@ -555,3 +555,72 @@ def test_pipelined_submit_wait_equals_synchronous_batches(det_mod, oracle):
     _compare_candidates([c for c in got[3] if c.frame == 2], oracle.detect(flat, batches[3][2]))
     assert len(det.detect(batches[0][0])) > 0              # synchronous calls work again
     det.hd.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_model_with_filters_of_different_sizes(det_mod, oracle, dtype):
+    """Filters of several sizes inside one model: the reference builds one engine per filter and sizes the part boxes
+    per mixture (src/SpatialConvolutionEngine.cpp:141-158, include/Parts.hpp:185-187).  Sizes 5 / 3 / 7 / 4 cycling over
+    the 12 filters of a 4-part x 3-mixture tree (even size: anchor k/2): responses of every filter, the candidates and
+    their per-mixture box sizes bit for bit against the oracle."""
+    model = M.synthetic_model(seed=17, pa=[0, 1, 1, 2], nmix=3, ksize=[5, 3, 7, 4], interval=5, thresh=-1e9, name="mixed-sizes")
+    flat = model.flatten()
+    assert sorted(set(int(k) for k in flat.filter_ksize)) == [3, 4, 5, 7]
+    im = synth.synthetic_frame(41, 150, 130, 3)
+    want = oracle.detect(flat, im, dtype=dtype)
+    model.thresh = float(np.sort([w["score"] for w in want])[-60])
+    flat = model.flatten()
+    want = oracle.detect(flat, im, dtype=dtype)
+    det = det_mod.PartsBasedDetector(device=0, dtype=dtype)
+    det.distributeModel(model)
+    got = det.detect(im)
+    _compare_candidates(got, want)
+    assert len({tuple(p[2:]) for c in got for p in c.parts.tolist()}) > 4          # several box sizes occur
+    feats, _ = oracle.features_pyramid(flat, im, dtype=dtype)
+    for l in (0, len(feats) - 1):
+        H, W = feats[l].shape[0], feats[l].shape[1] // 32
+        r = det.hd.get_stage(1, 0, l, H, W)
+        wr = oracle.responses(flat, feats[l])
+        assert r.dtype == wr.dtype and np.array_equal(r.view(np.uint8), wr.view(np.uint8))
+    det.hd.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_filter_shared_inside_a_component(det_mod, oracle, dtype):
+    """A filter id referenced by more than one (part, mixture) of a component: the reference keys the accumulated
+    scores by filter id (src/DynamicProgram.cpp:93,115-119,154-156; include/Parts.hpp:168-171), so such parts see each
+    other's children's messages in processing order.  Cases: two siblings sharing both filters, a child sharing a filter
+    with its own parent, two mixtures of one part pointing at the same filter -- rootv / rooti / Ix / Iy / Ik and the
+    candidates bit for bit against the oracle (which keeps `ncscores` exactly as the reference does)."""
+    from partsbaseddetector_amd import _lib
+    rng = np.random.default_rng(31)
+    for case in range(3):
+        model = M.synthetic_model(seed=23 + case, pa=[0, 1, 1, 2, 2, 3], nmix=2, interval=5, thresh=0.0, linear_def=True, name=f"shared-{case}")
+        fid = model.filterid[0]
+        if case == 0:
+            fid[2] = list(fid[1])                      # siblings 1 and 2 (children of the root) share both filters
+        elif case == 1:
+            fid[3][0] = fid[1][1]                      # part 3 shares a filter with its parent (part 1) ...
+            fid[5] = [fid[2][0], fid[2][0]]            # ... and part 5 uses its parent's (part 2) filter for both mixtures
+        else:
+            fid[0][1] = fid[0][0]                      # both root mixtures on one filter
+            fid[4] = list(fid[3])                      # siblings 3 and 4 share
+            fid[5][1] = fid[1][0]                      # a grandchild's filter = its grandparent's
+        flat = model.flatten()
+        hd = det_mod.Handle(flat, device=0, real_type=_lib.REAL_F32 if dtype == np.float32 else _lib.REAL_F64)
+        dp = det_mod.DynamicProgram(hd)
+        scores = [rng.standard_normal((flat.nfilters, h, w)).astype(dtype) for h, w in [(17, 23), (6, 9), (1, 5)]]
+        Ix, Iy, Ik, rootv, rooti = dp.min(scores)
+        for l, sc in enumerate(scores):
+            oIx, oIy, oIk, orv, ori = oracle.dp_min(flat, 0, sc)
+            assert np.array_equal(rootv[l][0].view(np.uint8), orv.view(np.uint8)), (case, l)
+            assert np.array_equal(rooti[l][0], ori), (case, l)
+            assert np.array_equal(Ix[l], oIx) and np.array_equal(Iy[l], oIy) and np.array_equal(Ik[l], oIk), (case, l)
+        hd.close()
+        im = synth.synthetic_frame(50 + case, 120, 100, 3)
+        want = oracle.detect(flat, im, dtype=dtype)
+        model.thresh = float(np.sort([w["score"] for w in want])[-30])
+        det = det_mod.PartsBasedDetector(device=0, dtype=dtype)
+        det.distributeModel(model)
+        _compare_candidates(det.detect(im), oracle.detect(model.flatten(), im, dtype=dtype))
+        det.hd.close()
