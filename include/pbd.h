@@ -116,7 +116,9 @@ int pbd_binsize(const pbd_handle *h);                      /* IFeatures::binsize
 int pbd_pyramid_plan(pbd_handle *h, int rows, int cols, int *nlevels, int *img_rows, int *img_cols,
                      int *feat_rows, int *feat_cols, float *scales);
 /* IFeatures::pyramid(im, pyrafeatures): feat[l] receives feat_rows[l] x (feat_cols[l]*flen) values of T.
- * stride_bytes: byte distance between image rows (cv::Mat::step). depth_code: 0 = 8-bit unsigned. */
+ * stride_bytes: byte distance between image rows (cv::Mat::step).  depth_code = cv::Mat::depth() of the image: 0 (CV_8U),
+ * 2 (CV_16U), 5 (CV_32F) or 6 (CV_64F) -- the four features<IT> instantiations of src/HOGFeatures.cpp:136-146; any other
+ * depth fails with PBD_ERR_UNSUPPORTED as the reference's CV_Error. */
 int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int channels,
                          size_t stride_bytes, int depth_code, void *const *feat);
 /* the resampled level images of the last pbd_features_pyramid / pbd_detect call (for tests) */
@@ -149,6 +151,10 @@ int pbd_dp_argmin(pbd_handle *h, const float *scales, int32_t *cand, int capacit
  * `depth` of the 3-argument overload is ignored by the reference (:91-93) and has no parameter here. */
 int pbd_detect(pbd_handle *h, const void *img, int rows, int cols, int channels, size_t stride_bytes,
                int32_t *cand, int capacity, int *ncand);
+/* The same for an image of any accepted depth (depth_code as in pbd_features_pyramid); pbd_detect is depth_code 0.
+ * The batch entry points take 8-bit frames. */
+int pbd_detect_typed(pbd_handle *h, const void *img, int rows, int cols, int channels, size_t stride_bytes,
+                     int depth_code, int32_t *cand, int capacity, int *ncand);
 /* New surface (the reference has no batch API): nframes equally-sized frames, results identical to
  * nframes pbd_detect calls, candidate `frame` field = index in the batch. */
 int pbd_detect_batch(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int channels,

@@ -53,6 +53,8 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.pbdo_detect_f32.restype = C.c_int
         _LIB.pbdo_detect_f64.restype = C.c_int
+        _LIB.pbdo_detect_d_f32.restype = C.c_int
+        _LIB.pbdo_detect_d_f64.restype = C.c_int
     return _LIB
 
 
@@ -80,6 +82,20 @@ def num_threads() -> int:
 
 def set_num_threads(n: int) -> None:
     lib().pbdo_set_num_threads(int(n))
+
+
+DEPTH_CODE = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 2, np.dtype(np.float32): 5, np.dtype(np.float64): 6}   # OpenCV's depth codes
+
+
+def _image(im):
+    """contiguous (rows, cols, cn) image of one of the depths HOGFeatures::pyramid accepts, and its depth code"""
+    im = np.asarray(im)
+    if im.dtype not in DEPTH_CODE:
+        im = im.astype(np.uint8)
+    im = np.ascontiguousarray(im)
+    if im.ndim == 2:
+        im = im[:, :, None]
+    return im, DEPTH_CODE[im.dtype]
 
 
 def pyramid_plan(rows, cols, sbin, interval):
@@ -120,33 +136,28 @@ def pyrdown_u8(src):
 
 
 def pyramid_images(im, sbin, interval):
-    im = np.ascontiguousarray(im, np.uint8)
-    if im.ndim == 2:
-        im = im[:, :, None]
+    im, depth = _image(im)
     r, c, cn = im.shape
     lr, lc, sc = pyramid_plan(r, c, sbin, interval)
     n = len(lr)
     tot = int(sum(int(a) * int(b) * cn for a, b in zip(lr, lc)))
-    out = np.empty(tot, np.uint8)
+    out = np.empty(tot, im.dtype)
     off = np.zeros(n + 1, np.int64)
     lr2, lc2, sc2 = np.zeros(MAX_LEVELS, np.int32), np.zeros(MAX_LEVELS, np.int32), np.zeros(MAX_LEVELS, np.float32)
-    lib().pbdo_pyramid_images_u8(_p(im, C.c_uint8), r, c, cn, C.c_size_t(c * cn), sbin, interval, _p(out, C.c_uint8),
-                                 _p(off, C.c_int64), _p(lr2, C.c_int), _p(lc2, C.c_int), _p(sc2, C.c_float))
+    lib().pbdo_pyramid_images(C.c_void_p(im.ctypes.data), depth, r, c, cn, C.c_size_t(c * cn), sbin, interval,
+                              C.c_void_p(out.ctypes.data), _p(off, C.c_int64), _p(lr2, C.c_int), _p(lc2, C.c_int), _p(sc2, C.c_float))
     imgs = [out[off[l]:off[l + 1]].reshape(lr[l], lc[l], cn) for l in range(n)]
     return imgs, sc
 
 
 def hog_features(im, sbin=4, norient=18, flen=32, dtype=np.float32):
-    im = np.ascontiguousarray(im, np.uint8)
-    if im.ndim == 2:
-        im = im[:, :, None]
+    im, depth = _image(im)
     r, c, cn = im.shape
     oh, ow = hog_dims(r, c, sbin)
     feat = np.empty((oh, ow * flen), dtype)
-    if dtype == np.float32:
-        lib().pbdo_hog_features_f32(_p(im, C.c_uint8), r, c, cn, C.c_size_t(c * cn), sbin, norient, flen, _p(feat, C.c_float))
-    else:
-        lib().pbdo_hog_features_f64(_p(im, C.c_uint8), r, c, cn, C.c_size_t(c * cn), sbin, norient, flen, _p(feat, C.c_double))
+    fn = lib().pbdo_hog_features_d_f32 if dtype == np.float32 else lib().pbdo_hog_features_d_f64
+    fn(C.c_void_p(im.ctypes.data), depth, r, c, cn, C.c_size_t(c * cn), sbin, norient, flen,
+       _p(feat, C.c_float if dtype == np.float32 else C.c_double))
     return feat
 
 
@@ -229,9 +240,7 @@ def dp_argmin(flat, c, level, scale, Ix, Iy, Ik, rootv, rooti, capacity=100000):
 
 def features_pyramid(flat, im, dtype=np.float32):
     """IFeatures::pyramid -> list of (H, W*flen) feature maps, scales."""
-    im = np.ascontiguousarray(im, np.uint8)
-    if im.ndim == 2:
-        im = im[:, :, None]
+    im, depth = _image(im)
     r, c, cn = im.shape
     lr, lc, _ = pyramid_plan(r, c, flat.sbin, flat.interval)
     n = len(lr)
@@ -242,9 +251,9 @@ def features_pyramid(flat, im, dtype=np.float32):
     orow, ocol = np.zeros(MAX_LEVELS, np.int32), np.zeros(MAX_LEVELS, np.int32)
     sc = np.zeros(MAX_LEVELS, np.float32)
     cm = c_model(flat)
-    fn = lib().pbdo_features_f32 if dtype == np.float32 else lib().pbdo_features_f64
+    fn = lib().pbdo_features_d_f32 if dtype == np.float32 else lib().pbdo_features_d_f64
     ct = C.c_float if dtype == np.float32 else C.c_double
-    got = fn(C.byref(cm), _p(im, C.c_uint8), r, c, cn, C.c_size_t(c * cn), _p(feat, ct), _p(off, C.c_int64),
+    got = fn(C.byref(cm), C.c_void_p(im.ctypes.data), depth, r, c, cn, C.c_size_t(c * cn), _p(feat, ct), _p(off, C.c_int64),
              _p(orow, C.c_int), _p(ocol, C.c_int), _p(sc, C.c_float))
     assert got == n
     feats = [feat[off[l]:off[l + 1]].reshape(dims[l][0], dims[l][1] * flat.flen) for l in range(n)]
@@ -267,17 +276,15 @@ def responses(flat, feat):
 
 def detect(flat, im, dtype=np.float32, capacity=200000, want_stage_ms=False):
     """PartsBasedDetector<T>::detect -> list of candidate dicts sorted by (level, component, y, x)."""
-    im = np.ascontiguousarray(im, np.uint8)
-    if im.ndim == 2:
-        im = im[:, :, None]
+    im, depth = _image(im)
     r, c, cn = im.shape
     hdr = (_Hdr * capacity)()
     mp = flat.max_parts
     rects = np.zeros((capacity, mp, 4), np.int32)
     ms = (C.c_double * 5)()
     cm = c_model(flat)
-    fn = lib().pbdo_detect_f32 if dtype == np.float32 else lib().pbdo_detect_f64
-    n = fn(C.byref(cm), _p(im, C.c_uint8), r, c, cn, C.c_size_t(c * cn), hdr, _p(rects, C.c_int), mp, capacity, ms)
+    fn = lib().pbdo_detect_d_f32 if dtype == np.float32 else lib().pbdo_detect_d_f64
+    n = fn(C.byref(cm), C.c_void_p(im.ctypes.data), depth, r, c, cn, C.c_size_t(c * cn), hdr, _p(rects, C.c_int), mp, capacity, ms)
     if n < 0:
         raise RuntimeError(f"oracle detect failed ({n})")
     cands = _unpack(hdr, rects, n, mp)

@@ -83,6 +83,29 @@ int pbdo_pyramid_images_u8(const uint8_t *im, int rows, int cols, int cn, size_t
                            int sbin, int interval, uint8_t *out, int64_t *img_offset,
                            int *lvl_rows, int *lvl_cols, float *scales);
 
+/* image depths HOGFeatures::pyramid accepts (src/HOGFeatures.cpp:136-146), OpenCV's depth codes */
+enum { PBDO_8U = 0, PBDO_16U = 2, PBDO_32F = 5, PBDO_64F = 6 };
+size_t pbdo_depth_size(int depth);
+/* depth-generic forms: strides, `out` and img_offset in ELEMENTS of the depth (third-party resampling, unpinned) */
+void pbdo_resize_linear(const void *src, int depth, int srows, int scols, int cn, size_t sstride, void *dst, int drows,
+                        int dcols, size_t dstride);
+void pbdo_pyrdown(const void *src, int depth, int srows, int scols, int cn, size_t sstride, void *dst, size_t dstride);
+int pbdo_pyramid_images(const void *im, int depth, int rows, int cols, int cn, size_t stride, int sbin, int interval,
+                        void *out, int64_t *img_offset, int *lvl_rows, int *lvl_cols, float *scales);
+void pbdo_hog_features_d_f32(const void *im, int depth, int rows, int cols, int cn, size_t stride, int sbin, int norient,
+                             int flen, float *feat);
+void pbdo_hog_features_d_f64(const void *im, int depth, int rows, int cols, int cn, size_t stride, int sbin, int norient,
+                             int flen, double *feat);
+int pbdo_features_d_f32(const pbdo_model *m, const void *im, int depth, int rows, int cols, int cn, size_t stride,
+                        float *feat, int64_t *feat_offset, int *out_rows, int *out_cols, float *scales);
+int pbdo_features_d_f64(const pbdo_model *m, const void *im, int depth, int rows, int cols, int cn, size_t stride,
+                        double *feat, int64_t *feat_offset, int *out_rows, int *out_cols, float *scales);
+int pbdo_detect_d_f32(const pbdo_model *m, const void *im, int depth, int rows, int cols, int cn, size_t stride,
+                      pbdo_candidate_hdr *hdr, int *rects, int max_parts, int capacity, double *stage_ms);
+int pbdo_detect_d_f64(const pbdo_model *m, const void *im, int depth, int rows, int cols, int cn, size_t stride,
+                      pbdo_candidate_hdr *hdr, int *rects, int max_parts, int capacity, double *stage_ms);
+
+
 /* ---- HOG: src/HOGFeatures.cpp:168-341 ---- */
 void pbdo_hog_dims(int rows, int cols, int sbin, int *out_rows, int *out_cols);
 void pbdo_hog_features_f32(const uint8_t *im, int rows, int cols, int cn, size_t stride,

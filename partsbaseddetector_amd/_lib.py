@@ -19,6 +19,8 @@ STATUS = {0: "PBD_OK", -1: "PBD_ERR_INVALID", -2: "PBD_ERR_UNSUPPORTED", -3: "PB
 REAL_F32, REAL_F64 = 0, 1
 CONV_EXACT, CONV_FMA, CONV_MFMA, CONV_MFMA_F16 = 0, 1, 2, 3
 STAGE_FEATURES, STAGE_RESPONSES, STAGE_ROOTV, STAGE_ROOTI = 0, 1, 2, 3
+# cv::Mat::depth() codes of the image depths HOGFeatures::pyramid accepts (src/HOGFeatures.cpp:136-146)
+DEPTH_CODE = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 2, np.dtype(np.float32): 5, np.dtype(np.float64): 6}
 KERNELS = ["k_resize", "k_pyrdown", "k_hog_hist", "k_hog_feat", "k_conv", "k_dt_rows", "k_dt_cols", "k_dp_combine",
            "k_dp_root", "k_argmin"]
 
@@ -27,7 +29,7 @@ SYMBOLS = [
     "pbd_create", "pbd_destroy", "pbd_last_error", "pbd_version", "pbd_candidate_stride", "pbd_binsize",
     "pbd_pyramid_plan", "pbd_features_pyramid", "pbd_get_pyramid_image", "pbd_conv_set_filters", "pbd_conv_pdf",
     "pbd_num_ptr_slots", "pbd_ptr_slot", "pbd_dp_min", "pbd_dp_argmin", "pbd_detect", "pbd_detect_batch",
-    "pbd_detect_batch_device", "pbd_detect_batch_submit", "pbd_detect_batch_wait", "pbd_get_stage", "pbd_profile_enable", "pbd_profile_reset", "pbd_profile_read",
+    "pbd_detect_batch_device", "pbd_detect_typed", "pbd_detect_batch_submit", "pbd_detect_batch_wait", "pbd_get_stage", "pbd_profile_enable", "pbd_profile_reset", "pbd_profile_read",
     "pbd_kernel_name", "pbd_synchronize",
 ]
 
@@ -94,6 +96,8 @@ def load():
     lib.pbd_dp_argmin.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     lib.pbd_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                                C.POINTER(C.c_int)]
+    lib.pbd_detect_typed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_int,
+                                     C.POINTER(C.c_int)]
     lib.pbd_detect_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_size_t,
                                      C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     lib.pbd_detect_batch_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_size_t]

@@ -110,6 +110,8 @@ struct Plan {
     DevTable<LevelDesc> d_lv;
     DevTable<ResizeTabX> d_tabx;
     DevTable<ResizeTabY> d_taby;
+    DevTable<ResizeTabXf> d_tabxf;   // the same mapping with float coefficients (16U / 32F / 64F images)
+    DevTable<ResizeTabYf> d_tabyf;
     DevTable<ConvTile> d_tiles, d_shaped;
     int nshaped[3] = {0, 0, 0};
     DevTable<int> d_row2level, d_rowoff, d_col2level, d_coloff;
@@ -118,7 +120,7 @@ struct Plan {
     DevTable<float> d_scales;
     void release()
     {
-        d_lv.release(); d_tabx.release(); d_taby.release(); d_tiles.release(); d_shaped.release();
+        d_lv.release(); d_tabx.release(); d_taby.release(); d_tabxf.release(); d_tabyf.release(); d_tiles.release(); d_shaped.release();
         d_row2level.release(); d_rowoff.release(); d_col2level.release(); d_coloff.release(); d_scales.release();
         d_stk_row_off.release(); d_stk_col_off.release();
     }
@@ -215,6 +217,7 @@ struct pbd_handle {
     std::vector<std::unique_ptr<Plan>> plans;
     Plan *cur = nullptr;
     int cur_frames = 0, cur_cn = 3;
+    int cur_depth = kDepth8U;        // image depth of the frames being processed (set by the entry point)
     bool have_features = false, have_resp = false, have_dp = false;
 
     // workspace
@@ -409,6 +412,8 @@ int get_image_plan(pbd_handle *h, int rows, int cols, Plan **out)
     P->lv.resize(n);
     std::vector<ResizeTabX> tabx;
     std::vector<ResizeTabY> taby;
+    std::vector<ResizeTabXf> tabxf;
+    std::vector<ResizeTabYf> tabyf;
     long long pix = 0, blk = 0, cell = 0;
     for (int l = 0; l < n; ++l) {
         LevelDesc &d = P->lv[l];
@@ -435,8 +440,10 @@ int get_image_plan(pbd_handle *h, int rows, int cols, Plan **out)
                 int sx = (int)floorf(fx);
                 fx -= (float)sx;
                 if (sx < 0) { fx = 0; sx = 0; }
-                if (sx >= cols - 1) { fx = 0; sx = cols - 1; }
+                const int last = sx >= cols - 1;
+                if (last) { fx = 0; sx = cols - 1; }
                 tabx.push_back({sx, sat_short_round((1.f - fx) * 2048), sat_short_round(fx * 2048)});
+                tabxf.push_back({sx, last, 1.f - fx, fx});
             }
             for (int dy = 0; dy < lr[l]; ++dy) {
                 float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -444,6 +451,7 @@ int get_image_plan(pbd_handle *h, int rows, int cols, Plan **out)
                 fy -= (float)sy;
                 const int y0 = std::min(std::max(sy, 0), rows - 1), y1 = std::min(std::max(sy + 1, 0), rows - 1);
                 taby.push_back({y0, y1, sat_short_round((1.f - fy) * 2048), sat_short_round(fy * 2048)});
+                tabyf.push_back({y0, y1, 1.f - fy, fy});
             }
         }
     }
@@ -451,6 +459,8 @@ int get_image_plan(pbd_handle *h, int rows, int cols, Plan **out)
     if (P->npix_resized == 0) P->npix_resized = pix;
     HIPCHK(h, P->d_tabx.upload(tabx));
     HIPCHK(h, P->d_taby.upload(taby));
+    HIPCHK(h, P->d_tabxf.upload(tabxf));
+    HIPCHK(h, P->d_tabyf.upload(tabyf));
     HIPCHK(h, finish_plan_tables(*P));
     // HOG coordinate table grows with the largest frame seen
     const int need = std::max(rows, cols) + 4 * h->sbin + 8;
@@ -846,7 +856,7 @@ int build_model(pbd_handle *h, const pbd_model *m)
 // [f0, f0+nb) on stream `st` (no allocation, no synchronisation inside).
 int alloc_features(pbd_handle *h, Plan &P, int nframes, int cn)
 {
-    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * cn + 4));   // +4: pixels are read as one 32-bit load
+    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * cn * depth_size(h->cur_depth) + 4));   // +4: 8-bit pixels are read as one 32-bit load
     HIPCHK(h, h->gmag.ensure((size_t)nframes * P.pix_per_frame * h->rs));
     HIPCHK(h, h->gori.ensure((size_t)nframes * P.pix_per_frame));
     HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * h->rs));
@@ -861,6 +871,7 @@ void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int cn, int f
     pp.lv = P.d_lv.d; pp.nlevels = P.nlevels; pp.interval = std::min(P.interval, P.nlevels); pp.cn = cn; pp.frame0 = f0;
     pp.pix_per_frame = P.pix_per_frame; pp.pyr = h->pyr.as<uint8_t>(); pp.frames = static_cast<const uint8_t *>(d_frames);
     pp.rows = P.rows; pp.cols = P.cols; pp.tabx = P.d_tabx.d; pp.taby = P.d_taby.d;
+    pp.depth = h->cur_depth; pp.tabxf = P.d_tabxf.d; pp.tabyf = P.d_tabyf.d;
     {
         ProfScope ps(h, PBD_K_RESIZE, st);
         launch_resize(pp, nb, P.npix_resized, st);
@@ -875,7 +886,7 @@ void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int cn, int f
     HogParams hp{};
     hp.lv = P.d_lv.d; hp.nlevels = P.nlevels; hp.cn = cn; hp.sbin = h->sbin; hp.frame0 = f0;
     hp.pix_per_frame = P.pix_per_frame; hp.blk_per_frame = P.blk_per_frame; hp.cell_per_frame = P.cell_per_frame;
-    hp.pyr = h->pyr.as<uint8_t>(); hp.coord = h->d_coord.p;
+    hp.pyr = h->pyr.as<uint8_t>(); hp.depth = h->cur_depth; hp.coord = h->d_coord.p;
     hp.gmag = h->gmag.p; hp.gori = h->gori.as<uint8_t>();
     hp.hist = h->hist.p; hp.norm = h->norm.p; hp.feat = h->feat.p;
     {
@@ -1158,9 +1169,9 @@ int detect_device(pbd_handle *h, int nframes, const void *d_frames, int rows, in
 
 int upload_frames(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int cn, size_t stride_bytes)
 {
-    const size_t row_bytes = (size_t)cols * cn;
+    const size_t row_bytes = (size_t)cols * cn * depth_size(h->cur_depth);
     if (stride_bytes < row_bytes) return fail(h, PBD_ERR_INVALID, "stride %zu < row bytes %zu", stride_bytes, row_bytes);
-    HIPCHK(h, h->frames.ensure((size_t)nframes * rows * row_bytes));
+    HIPCHK(h, h->frames.ensure((size_t)nframes * rows * row_bytes + 4));
     for (int i = 0; i < nframes; ++i)
         HIPCHK(h, hipMemcpy2DAsync(h->frames.as<uint8_t>() + (size_t)i * rows * row_bytes, row_bytes, imgs[i], stride_bytes,
                                    row_bytes, rows, hipMemcpyHostToDevice, h->stream));
@@ -1321,7 +1332,9 @@ int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int
         if (!h || !img || !feat) return PBD_ERR_INVALID;
         if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
         (void)hipSetDevice(h->cfg.device);
-        if (depth_code != 0) return fail(h, PBD_ERR_UNSUPPORTED, "image depth code %d: only 8-bit unsigned is supported", depth_code);
+        if (!depth_size(depth_code))
+            return fail(h, PBD_ERR_UNSUPPORTED, "image depth code %d: 0 (8U), 2 (16U), 5 (32F) or 6 (64F), src/HOGFeatures.cpp:136-146", depth_code);
+        h->cur_depth = depth_code;
         if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
         Plan *P = nullptr;
         int rc = get_image_plan(h, rows, cols, &P);
@@ -1352,8 +1365,9 @@ int pbd_get_pyramid_image(pbd_handle *h, int frame, int level, uint8_t *dst)
         Plan &P = *h->cur;
         if (frame < 0 || frame >= h->cur_frames || level < 0 || level >= P.nlevels) return fail(h, PBD_ERR_INVALID, "frame/level out of range");
         const LevelDesc &d = P.lv[level];
-        HIPCHK(h, hipMemcpyAsync(dst, h->pyr.as<uint8_t>() + ((size_t)frame * P.pix_per_frame + d.img_off) * h->cur_cn,
-                                 (size_t)d.img_rows * d.img_cols * h->cur_cn, hipMemcpyDeviceToHost, h->stream));
+        const size_t es = depth_size(h->cur_depth);
+        HIPCHK(h, hipMemcpyAsync(dst, h->pyr.as<uint8_t>() + ((size_t)frame * P.pix_per_frame + d.img_off) * h->cur_cn * es,
+                                 (size_t)d.img_rows * d.img_cols * h->cur_cn * es, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return PBD_OK;
     });
@@ -1480,6 +1494,7 @@ int pbd_detect_batch(pbd_handle *h, int nframes, const void *const *imgs, int ro
         if (nframes < 1 || nframes > h->cfg.max_batch)
             return fail(h, PBD_ERR_INVALID, "nframes %d outside 1..max_batch %d", nframes, h->cfg.max_batch);
         if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
+        h->cur_depth = kDepth8U;
         int rc = upload_frames(h, nframes, imgs, rows, cols, channels, stride_bytes);
         if (rc != PBD_OK) return rc;
         return detect_device(h, nframes, h->frames.p, rows, cols, channels, cand, capacity, ncand);
@@ -1524,6 +1539,7 @@ int pbd_detect_batch_submit(pbd_handle *h, int nframes, const void *const *imgs,
         HIPCHK(h, hipEventRecord(S.copied, h->stream_copy));
         HIPCHK(h, hipStreamWaitEvent(h->stream, S.copied, 0));
         Plan *P = nullptr;
+        h->cur_depth = kDepth8U;
         int rc = enqueue_detect(h, nframes, S.frames.p, rows, cols, channels, &P);
         if (rc != PBD_OK) return rc;
         HIPCHK(h, hipMemsetAsync(S.count.p, 0, sizeof(int), h->stream));
@@ -1569,7 +1585,25 @@ int pbd_detect_batch_device(pbd_handle *h, int nframes, const void *d_frames, in
     return guarded(h, [&]() -> int {
         if (!h || !d_frames) return PBD_ERR_INVALID;
         (void)hipSetDevice(h->cfg.device);
+        h->cur_depth = kDepth8U;
         return detect_device(h, nframes, d_frames, rows, cols, channels, cand, capacity, ncand);
+    });
+}
+
+int pbd_detect_typed(pbd_handle *h, const void *img, int rows, int cols, int channels, size_t stride_bytes, int depth_code,
+                     int32_t *cand, int capacity, int *ncand)
+{
+    return guarded(h, [&]() -> int {
+        if (!h || !img || !cand || !ncand) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
+        if (!depth_size(depth_code))
+            return fail(h, PBD_ERR_UNSUPPORTED, "image depth code %d: 0 (8U), 2 (16U), 5 (32F) or 6 (64F), src/HOGFeatures.cpp:136-146", depth_code);
+        if (channels != 1 && channels != 3) return fail(h, PBD_ERR_INVALID, "channels %d (1 or 3, src/HOGFeatures.cpp:171)", channels);
+        h->cur_depth = depth_code;
+        int rc = upload_frames(h, 1, &img, rows, cols, channels, stride_bytes);
+        if (rc != PBD_OK) return rc;
+        return detect_device(h, 1, h->frames.p, rows, cols, channels, cand, capacity, ncand);
     });
 }
 

@@ -29,6 +29,12 @@ struct LevelDesc {
 // resize tables (cv::resize INTER_LINEAR 8U fixed point)
 struct ResizeTabX { int sx; short a0, a1; };
 struct ResizeTabY { int y0, y1; short b0, b1; };
+// the same mapping with float coefficients (16U / 32F / 64F images); last: sx is the last source column (D = S[sx])
+struct ResizeTabXf { int sx, last; float a0, a1; };
+struct ResizeTabYf { int y0, y1; float b0, b1; };
+// image depths HOGFeatures::pyramid accepts (src/HOGFeatures.cpp:136-146), OpenCV's depth codes
+enum { kDepth8U = 0, kDepth16U = 2, kDepth32F = 5, kDepth64F = 6 };
+inline size_t depth_size(int depth) { return depth == kDepth8U ? 1 : depth == kDepth16U ? 2 : depth == kDepth32F ? 4 : depth == kDepth64F ? 8 : 0; }
 
 // bilinear cell weights of a pixel coordinate (src/HOGFeatures.cpp:252-259), depends on sbin only
 template <typename R> struct HogCoordT { int ip; R v0, v1; };
@@ -104,11 +110,14 @@ struct PyrParams {
     int nlevels, interval, cn;
     int frame0;                   // first frame of this launch (grid index 0)
     long long pix_per_frame;      // pixels (not bytes) of all level images of one frame
-    uint8_t *pyr;                 // [frames][pix_per_frame*cn]
+    uint8_t *pyr;                 // [frames][pix_per_frame*cn] elements of the image depth
     const uint8_t *frames;        // [frames][rows*cols*cn] dense
     int rows, cols;
     const ResizeTabX *tabx;
     const ResizeTabY *taby;
+    int depth;                    // kDepth8U (fixed-point resampling, the tables above) or 16U / 32F / 64F (tables below)
+    const ResizeTabXf *tabxf;
+    const ResizeTabYf *tabyf;
 };
 
 struct HogParams {
@@ -117,6 +126,7 @@ struct HogParams {
     int frame0;
     long long pix_per_frame, blk_per_frame, cell_per_frame;
     const uint8_t *pyr;
+    int depth;                    // image depth of `pyr`
     const void *coord;            // HogCoordT<R>[]
     void *gmag;                   // R [frames][pix_per_frame] gradient magnitude per image pixel
     uint8_t *gori;                // [frames][pix_per_frame] snapped orientation 0..17

@@ -89,10 +89,54 @@ __global__ __launch_bounds__(256) void k_resize(PyrParams p, long long npix)
     }
 }
 
+// The other depths (16U, 32F, 64F): cv::resize keeps float coefficients and works in float (double for 64F);
+// D = S[sx]*a0 + S[sx+1]*a1 (exactly S[sx] at the last column), dst = cast(R0*b0 + R1*b1), cast = cvRound + clamp for
+// 16U (third-party arithmetic restated from OpenCV's generic code path; unpinned, as for 8-bit).
+template <typename PT, typename WT> __device__ __forceinline__ PT resize_cast(WT v);
+template <> __device__ __forceinline__ uint16_t resize_cast<uint16_t, float>(float v)
+{
+    const int iv = __float2int_rn(v);
+    return (uint16_t)(iv < 0 ? 0 : iv > 65535 ? 65535 : iv);
+}
+template <> __device__ __forceinline__ float resize_cast<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ double resize_cast<double, double>(double v) { return v; }
+
+template <typename PT, typename WT>
+__global__ __launch_bounds__(256) void k_resize_t(PyrParams p, long long npix)
+{
+    __shared__ long long s_off[PBD_MAX_LEVELS];
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = find_level_blk<0>(p.lv, 0, p.interval, idx, s_off);
+    if (idx >= npix) return;
+    const int frame = p.frame0 + blockIdx.y;
+    const LevelDesc d = p.lv[l];
+    const int local = (int)(idx - d.img_off);
+    const int dy = local / d.img_cols, dx = local - dy * d.img_cols;
+    const ResizeTabXf tx = p.tabxf[d.tab_x + dx];
+    const ResizeTabYf ty = p.tabyf[d.tab_y + dy];
+    const int cn = p.cn;
+    const PT *src = reinterpret_cast<const PT *>(p.frames) + (size_t)frame * p.rows * p.cols * cn;
+    const PT *S0 = src + (size_t)ty.y0 * p.cols * cn, *S1 = src + (size_t)ty.y1 * p.cols * cn;
+    PT *D = reinterpret_cast<PT *>(p.pyr) + ((size_t)frame * p.pix_per_frame + d.img_off + local) * cn;
+    for (int c = 0; c < cn; ++c) {
+        WT r0, r1;
+        if (tx.last) {
+            r0 = (WT)S0[tx.sx * cn + c] * (WT)1; r1 = (WT)S1[tx.sx * cn + c] * (WT)1;
+        } else {
+            r0 = (WT)S0[tx.sx * cn + c] * (WT)tx.a0 + (WT)S0[(tx.sx + 1) * cn + c] * (WT)tx.a1;
+            r1 = (WT)S1[tx.sx * cn + c] * (WT)tx.a0 + (WT)S1[(tx.sx + 1) * cn + c] * (WT)tx.a1;
+        }
+        D[c] = resize_cast<PT, WT>(r0 * (WT)ty.b0 + r1 * (WT)ty.b1);
+    }
+}
+
 void launch_resize(const PyrParams &p, int nframes, long long npix, hipStream_t s)
 {
     dim3 grid((unsigned)((npix + 255) / 256), nframes);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, p, npix);
+    if (p.depth == kDepth16U) hipLaunchKernelGGL((k_resize_t<uint16_t, float>), grid, dim3(256), 0, s, p, npix);
+    else if (p.depth == kDepth32F) hipLaunchKernelGGL((k_resize_t<float, float>), grid, dim3(256), 0, s, p, npix);
+    else if (p.depth == kDepth64F) hipLaunchKernelGGL((k_resize_t<double, double>), grid, dim3(256), 0, s, p, npix);
+    else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, p, npix);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -154,11 +198,53 @@ __global__ __launch_bounds__(256) void k_pyrdown(PyrParams p, int first_level, i
     }
 }
 
+// The other depths: 16U integer as 8-bit; 32F / 64F the same taps in the pixel type, row = s2*6 + (s1+s3)*4 + s0 + s4,
+// dst = (r2*6 + (r1+r3)*4 + r0 + r4) * (1/256).
+template <typename PT, typename WT> __device__ __forceinline__ PT pyr_finish(WT v);
+template <> __device__ __forceinline__ uint16_t pyr_finish<uint16_t, int>(int v) { return (uint16_t)((v + 128) >> 8); }
+template <> __device__ __forceinline__ float pyr_finish<float, float>(float v) { return v * (1.f / 256.f); }
+template <> __device__ __forceinline__ double pyr_finish<double, double>(double v) { return v * (1. / 256.); }
+
+template <typename PT, typename WT>
+__global__ __launch_bounds__(256) void k_pyrdown_t(PyrParams p, int first_level, int last_level, long long base, long long npix)
+{
+    __shared__ long long s_off[PBD_MAX_LEVELS];
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = find_level_blk<0>(p.lv, first_level, last_level, idx + base, s_off);
+    if (idx >= npix) return;
+    const int frame = p.frame0 + blockIdx.y;
+    const LevelDesc d = p.lv[l];
+    const LevelDesc sd = p.lv[d.src_level];
+    const int local = (int)(idx + base - d.img_off);
+    const int y = local / d.img_cols, x = local - y * d.img_cols;
+    const int cn = p.cn;
+    const PT *S = reinterpret_cast<const PT *>(p.pyr) + ((size_t)frame * p.pix_per_frame + sd.img_off) * cn;
+    PT *D = reinterpret_cast<PT *>(p.pyr) + ((size_t)frame * p.pix_per_frame + d.img_off + local) * cn;
+    int xs[5], ys[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        xs[k] = reflect101(2 * x - 2 + k, sd.img_cols) * cn;
+        ys[k] = reflect101(2 * y - 2 + k, sd.img_rows);
+    }
+    for (int c = 0; c < cn; ++c) {
+        WT r[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const PT *R = S + (size_t)ys[k] * sd.img_cols * cn + c;
+            r[k] = (WT)R[xs[2]] * 6 + ((WT)R[xs[1]] + (WT)R[xs[3]]) * 4 + (WT)R[xs[0]] + (WT)R[xs[4]];
+        }
+        D[c] = pyr_finish<PT, WT>(r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]);
+    }
+}
+
 void launch_pyrdown_range(const PyrParams &p, int nframes, int first_level, int last_level, long long base,
                           long long npix, hipStream_t s)
 {
     dim3 grid((unsigned)((npix + 255) / 256), nframes);
-    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+    if (p.depth == kDepth16U) hipLaunchKernelGGL((k_pyrdown_t<uint16_t, int>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+    else if (p.depth == kDepth32F) hipLaunchKernelGGL((k_pyrdown_t<float, float>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+    else if (p.depth == kDepth64F) hipLaunchKernelGGL((k_pyrdown_t<double, double>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+    else hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -211,6 +297,67 @@ __global__ __launch_bounds__(256) void k_hog_grad(HogParams p)
         const R vg = dxg * dxg + dyg * dyg;
         dy = (R)(px_ch(pd, 2) - px_ch(pu, 2));
         dx = (R)(px_ch(pr, 2) - px_ch(pl, 2));
+        v = dx * dx + dy * dy;
+        if (vg > v) { v = vg; dx = dxg; dy = dyg; }
+        if (vb > v) { v = vb; dx = dxb; dy = dyb; }
+    }
+    R best_dot = (R)0;
+    int best_o = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const R dot = uu[k] * dx + vv[k] * dy;
+        if (dot > best_dot) { best_dot = dot; best_o = k; }
+        else if (-dot > best_dot) { best_dot = -dot; best_o = k + 9; }
+    }
+    static_cast<R *>(p.gmag)[o] = real_sqrt<R>(v);
+    p.gori[o] = (uint8_t)best_o;
+}
+
+// The same for 16U / 32F / 64F pixels (features<uint16_t|float|double>, src/HOGFeatures.cpp:136-146): the difference is
+// taken in the pixel type (integers promote to int, float / double subtract as such) and then converted to T.
+template <typename R, typename PT> __device__ __forceinline__ R pix_diff(PT a, PT b);
+template <> __device__ __forceinline__ float pix_diff<float, uint16_t>(uint16_t a, uint16_t b) { return (float)((int)a - (int)b); }
+template <> __device__ __forceinline__ double pix_diff<double, uint16_t>(uint16_t a, uint16_t b) { return (double)((int)a - (int)b); }
+template <> __device__ __forceinline__ float pix_diff<float, float>(float a, float b) { return a - b; }
+template <> __device__ __forceinline__ double pix_diff<double, float>(float a, float b) { return (double)(a - b); }
+template <> __device__ __forceinline__ float pix_diff<float, double>(double a, double b) { return (float)(a - b); }
+template <> __device__ __forceinline__ double pix_diff<double, double>(double a, double b) { return a - b; }
+
+template <typename R, typename PT>
+__global__ __launch_bounds__(256) void k_hog_grad_t(HogParams p)
+{
+    __shared__ long long s_off[PBD_MAX_LEVELS];
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = find_level_blk<0>(p.lv, 0, p.nlevels, idx, s_off);
+    if (idx >= p.pix_per_frame) return;
+    const int frame = p.frame0 + blockIdx.y;
+    const LevelDesc d = p.lv[l];
+    const int local = (int)(idx - d.img_off);
+    const int rows = d.img_rows, cols = d.img_cols;
+    const int ys = local / cols, xs = local - ys * cols;
+    const size_t o = (size_t)frame * p.pix_per_frame + idx;
+    if (xs < 1 || ys < 1 || xs > cols - 2 || ys > rows - 2) return;
+    const int cn = p.cn;
+    const PT *im = reinterpret_cast<const PT *>(p.pyr) + ((size_t)frame * p.pix_per_frame + d.img_off) * cn;
+    const size_t stride = (size_t)cols * cn;
+    const R uu[9] = {(R)1.000, (R)0.9397, (R)0.7660, (R)0.5000, (R)0.1736, (R)-0.1736, (R)-0.5000, (R)-0.7660, (R)-0.9397};
+    const R vv[9] = {(R)0.000, (R)0.3420, (R)0.6428, (R)0.8660, (R)0.9848, (R)0.9848, (R)0.8660, (R)0.6428, (R)0.3420};
+    R dx, dy, v;
+    if (cn == 1) {
+        const PT *s = im + xs + (size_t)ys * stride;
+        dy = pix_diff<R, PT>(s[stride], *(s - stride));
+        dx = pix_diff<R, PT>(s[1], s[-1]);
+        v = dx * dx + dy * dy;
+    } else {
+        const PT *s = im + 3 * xs + (size_t)ys * stride;
+        const R dyb = pix_diff<R, PT>(s[stride], *(s - stride));
+        const R dxb = pix_diff<R, PT>(s[3], s[-3]);
+        const R vb = dxb * dxb + dyb * dyb;
+        const R dyg = pix_diff<R, PT>(s[1 + stride], *(s + 1 - stride));
+        const R dxg = pix_diff<R, PT>(s[4], s[-2]);
+        const R vg = dxg * dxg + dyg * dyg;
+        dy = pix_diff<R, PT>(s[2 + stride], *(s + 2 - stride));
+        dx = pix_diff<R, PT>(s[5], s[-1]);
         v = dx * dx + dy * dy;
         if (vg > v) { v = vg; dx = dxg; dy = dyg; }
         if (vb > v) { v = vb; dx = dxb; dy = dyb; }
@@ -337,8 +484,17 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
 void launch_hog_hist(const HogParams &p, int nframes, bool f64, hipStream_t s)
 {
     dim3 gridp((unsigned)((p.pix_per_frame + 255) / 256), nframes);
-    if (f64) hipLaunchKernelGGL(k_hog_grad<double>, gridp, dim3(256), 0, s, p);
+#define PBD_GRAD(PT)                                                                            \
+    do {                                                                                        \
+        if (f64) hipLaunchKernelGGL((k_hog_grad_t<double, PT>), gridp, dim3(256), 0, s, p);     \
+        else hipLaunchKernelGGL((k_hog_grad_t<float, PT>), gridp, dim3(256), 0, s, p);          \
+    } while (0)
+    if (p.depth == kDepth16U) PBD_GRAD(uint16_t);
+    else if (p.depth == kDepth32F) PBD_GRAD(float);
+    else if (p.depth == kDepth64F) PBD_GRAD(double);
+    else if (f64) hipLaunchKernelGGL(k_hog_grad<double>, gridp, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_hog_grad<float>, gridp, dim3(256), 0, s, p);
+#undef PBD_GRAD
     dim3 grid((unsigned)((p.blk_per_frame + 255) / 256), nframes);
     if (f64) hipLaunchKernelGGL((k_hog_hist<double, 0>), grid, dim3(256), 0, s, p);
     else if (p.sbin == 4) hipLaunchKernelGGL((k_hog_hist<float, 4>), grid, dim3(256), 0, s, p);

@@ -178,28 +178,30 @@ class HOGFeatures:
 
     def pyramid(self, im: np.ndarray) -> List[np.ndarray]:
         """pyramid(im, pyrafeatures): list of (H, W*flen) maps of T, fine to coarse."""
-        if im.dtype != np.uint8:
-            # src/HOGFeatures.cpp:136-146 accepts 8U/16U/32F/64F; only 8-bit is built here
-            raise PbdError(-2, f"image dtype {im.dtype}: only uint8 is supported")
+        if im.dtype not in _lib.DEPTH_CODE:
+            # src/HOGFeatures.cpp:136-146: 8U / 16U / 32F / 64F, anything else is CV_StsUnsupportedFormat
+            raise PbdError(-2, f"image dtype {im.dtype}: uint8, uint16, float32 or float64")
         if im.ndim == 2:
             im = im[:, :, None]
         rows, cols, cn = im.shape
-        if not im.flags.c_contiguous and not (im.strides[2] == 1 and im.strides[1] == cn):
+        es = im.dtype.itemsize
+        if not im.flags.c_contiguous and not (im.strides[2] == es and im.strides[1] == cn * es):
             im = np.ascontiguousarray(im)
         plan = self.hd.plan(rows, cols)
         feats = [np.empty((int(r), int(c) * self.hd.flat.flen), self.hd.dtype)
                  for r, c in zip(plan["feat_rows"], plan["feat_cols"])]
         arr = _lib.ptr_array(feats)
-        self.hd.check(self.hd.lib.pbd_features_pyramid(self.hd.h, im.ctypes.data, rows, cols, cn, im.strides[0], 0, arr))
+        self.hd.check(self.hd.lib.pbd_features_pyramid(self.hd.h, im.ctypes.data, rows, cols, cn, im.strides[0],
+                                                       _lib.DEPTH_CODE[im.dtype], arr))
         self._scales = plan["scales"]
         return feats
 
-    def level_images(self, rows: int, cols: int, cn: int) -> List[np.ndarray]:
+    def level_images(self, rows: int, cols: int, cn: int, dtype=np.uint8) -> List[np.ndarray]:
         """the resampled pyramid images of the last pyramid()/detect() call (frame 0), for tests"""
         plan = self.hd.plan(rows, cols)
         out = []
         for l in range(plan["nlevels"]):
-            img = np.empty((int(plan["img_rows"][l]), int(plan["img_cols"][l]), cn), np.uint8)
+            img = np.empty((int(plan["img_rows"][l]), int(plan["img_cols"][l]), cn), dtype)
             self.hd.check(self.hd.lib.pbd_get_pyramid_image(self.hd.h, 0, l, img.ctypes.data))
             out.append(img)
         return out
@@ -296,18 +298,23 @@ class PartsBasedDetector:
     def detect(self, im: np.ndarray, depth: Optional[np.ndarray] = None, capacity: Optional[int] = None) -> List[Candidate]:
         """detect(im[, depth], candidates); `depth` is ignored exactly as in the reference (:91-93)."""
         self._need()
-        if im.dtype != np.uint8:
-            raise PbdError(-2, f"image dtype {im.dtype}: only uint8 is supported")
+        if im.dtype not in _lib.DEPTH_CODE:
+            raise PbdError(-2, f"image dtype {im.dtype}: uint8, uint16, float32 or float64 (src/HOGFeatures.cpp:136-146)")
         if im.ndim == 2:
             im = im[:, :, None]
-        if not (im.strides[2] == 1 and im.strides[1] == im.shape[2]):
+        es = im.dtype.itemsize
+        if not (im.strides[2] == es and im.strides[1] == im.shape[2] * es):
             im = np.ascontiguousarray(im)
         rows, cols, cn = im.shape
         cap = capacity or self.hd.max_candidates
         buf = np.zeros(cap * self.hd.stride, np.int32)
         n = C.c_int()
-        self.hd.check(self.hd.lib.pbd_detect(self.hd.h, im.ctypes.data, rows, cols, cn, im.strides[0], buf.ctypes.data,
-                                             cap, C.byref(n)))
+        if im.dtype == np.uint8:
+            self.hd.check(self.hd.lib.pbd_detect(self.hd.h, im.ctypes.data, rows, cols, cn, im.strides[0], buf.ctypes.data,
+                                                 cap, C.byref(n)))
+        else:
+            self.hd.check(self.hd.lib.pbd_detect_typed(self.hd.h, im.ctypes.data, rows, cols, cn, im.strides[0],
+                                                       _lib.DEPTH_CODE[im.dtype], buf.ctypes.data, cap, C.byref(n)))
         self.features_._scales = self.hd.plan(rows, cols)["scales"]
         return self.hd.unpack_candidates(buf, n.value)
 

@@ -217,7 +217,7 @@ def test_errors(det_mod):
     with pytest.raises(PbdError):
         det.detect(np.zeros((10, 10, 3), np.uint8))            # too small for one octave
     with pytest.raises(PbdError):
-        det.detect(np.zeros((100, 100, 3), np.float32))        # unsupported depth
+        det.detect(np.zeros((100, 100, 3), np.int32))          # unsupported depth (CV_32S: src/HOGFeatures.cpp:141-145)
     with pytest.raises(PbdError):
         det.detect(np.zeros((100, 100, 2), np.uint8))          # channels must be 1 or 3
     with pytest.raises(PbdError) as e:
@@ -624,3 +624,41 @@ def test_filter_shared_inside_a_component(det_mod, oracle, dtype):
         det.distributeModel(model)
         _compare_candidates(det.detect(im), oracle.detect(model.flatten(), im, dtype=dtype))
         det.hd.close()
+
+
+@pytest.mark.parametrize("IT", [np.uint16, np.float32, np.float64])
+def test_image_depths_16u_32f_64f(det_mod, oracle, IT):
+    """HOGFeatures::pyramid on the other depths it accepts (src/HOGFeatures.cpp:136-146: features<uint16_t|float|double>),
+    for T = float and T = double, colour and grey: level images, features of every level and the end-to-end candidates
+    bit for bit against the oracle (the resampling of these depths is third-party arithmetic, restated: unpinned)."""
+    from partsbaseddetector_amd import _lib
+    rng = np.random.default_rng(11)
+    for cn in (3, 1):
+        base = synth.synthetic_frame(15, 110, 150, cn).astype(np.float64)
+        if cn == 1:
+            base = base.reshape(110, 150, 1)
+        if IT == np.uint16:
+            im = (base * 257 + rng.integers(0, 200, base.shape)).astype(np.uint16)      # genuine 16-bit range
+        else:
+            im = (base / 255.0 + rng.random(base.shape) * 1e-3).astype(IT)            # [0, 1] floats, as a float image pipeline would hand over
+        for T in (np.float32, np.float64):
+            model = M.synthetic_tiny_model(thresh=-1e9)
+            flat = model.flatten()
+            hd = det_mod.Handle(flat, device=0, real_type=_lib.REAL_F32 if T == np.float32 else _lib.REAL_F64)
+            eng = det_mod.HOGFeatures(hd)
+            got = eng.pyramid(im)
+            want, scales = oracle.features_pyramid(flat, im, dtype=T)
+            assert len(got) == len(want) and np.array_equal(eng.scales(), scales)
+            imgs_want, _ = oracle.pyramid_images(im, flat.sbin, flat.interval)
+            imgs_got = eng.level_images(110, 150, cn, IT)
+            for l, (a, b) in enumerate(zip(imgs_got, imgs_want)):
+                assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), (cn, T, "image level", l)
+            for l, (a, b) in enumerate(zip(got, want)):
+                assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), (cn, T, "features level", l)
+            hd.close()
+            cands = oracle.detect(flat, im, dtype=T)
+            model.thresh = float(np.sort([w["score"] for w in cands])[-25])
+            det = det_mod.PartsBasedDetector(device=0, dtype=T)
+            det.distributeModel(model)
+            _compare_candidates(det.detect(im), oracle.detect(model.flatten(), im, dtype=T))
+            det.hd.close()

@@ -294,3 +294,100 @@ def test_f64_path_close_to_f32(oracle):
     common = set(ka) & set(kb)
     assert len(common) > 0.95 * max(len(ka), len(kb))
     assert max(abs(ka[k] - kb[k]) for k in common) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
+# image depths other than 8-bit (src/HOGFeatures.cpp:136-146: features<uint16_t|float|double>)
+# ---------------------------------------------------------------------------------------------------
+def test_hog_of_wider_depths_equals_8bit_on_the_same_values(oracle):
+    """The gradient is `*(s+a) - *(s-b)` in the pixel type: for 8-bit-valued pixels stored as uint16 / float / double
+    the differences are the same numbers, so features<IT> must give the features<uint8_t> result bit for bit."""
+    im8 = synth.synthetic_frame(5, 70, 93, 3)
+    for T in (np.float32, np.float64):
+        want = oracle.hog_features(im8, 4, 18, 32, T)
+        for IT in (np.uint16, np.float32, np.float64):
+            got = oracle.hog_features(im8.astype(IT), 4, 18, 32, T)
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (T, IT)
+    # and a genuinely 16-bit image: scaling every pixel by 256 scales the unnormalised gradients by 256, which the
+    # four block normalisations remove up to the 1e-4 epsilon -> same features within 1e-4
+    a = oracle.hog_features(im8, 4, 18, 32, np.float64)
+    b = oracle.hog_features(im8.astype(np.uint16) * 256, 4, 18, 32, np.float64)
+    assert np.abs(a - b).max() < 2e-4
+
+
+def _np_pyrdown(src, wt, finish):
+    r, c, cn = src.shape
+    dr, dc = (r + 1) // 2, (c + 1) // 2
+    def refl(p, n):
+        if n == 1:
+            return 0
+        while p < 0 or p >= n:
+            p = -p if p < 0 else 2 * n - 2 - p
+        return p
+    s = src.astype(wt)
+    rows = np.zeros((r, dc, cn), wt)
+    for x in range(dc):
+        x0, x1, x2, x3, x4 = refl(2 * x - 2, c), refl(2 * x - 1, c), 2 * x, refl(2 * x + 1, c), refl(2 * x + 2, c)
+        rows[:, x] = ((s[:, x2] * wt(6) + (s[:, x1] + s[:, x3]) * wt(4)) + s[:, x0]) + s[:, x4]
+    out = np.zeros((dr, dc, cn), wt)
+    for y in range(dr):
+        y0, y1, y2, y3, y4 = refl(2 * y - 2, r), refl(2 * y - 1, r), refl(2 * y, r), refl(2 * y + 1, r), refl(2 * y + 2, r)
+        out[y] = ((rows[y2] * wt(6) + (rows[y1] + rows[y3]) * wt(4)) + rows[y0]) + rows[y4]
+    return finish(out)
+
+
+@pytest.mark.parametrize("IT", [np.uint16, np.float32, np.float64])
+def test_pyramid_of_wider_depths_against_numpy(oracle, IT):
+    """pyrDown (levels >= interval) against an independent numpy statement of the same taps and operation order;
+    level 0 of the pyramid (resize to the same size) is the image itself; 16U-valued-as-8U equals the 8-bit pyramid."""
+    rng = np.random.default_rng(3)
+    if IT == np.uint16:
+        im = rng.integers(0, 65536, (61, 77, 3)).astype(np.uint16)
+    else:
+        im = (rng.random((61, 77, 3)) * 255).astype(IT)
+    imgs, scales = oracle.pyramid_images(im, 4, 3)
+    assert imgs[0].dtype == IT and np.array_equal(imgs[0], im)
+    for l in range(3, len(imgs)):
+        if IT == np.uint16:
+            want = _np_pyrdown(imgs[l - 3], np.int64, lambda v: ((v + 128) >> 8).astype(np.uint16))
+        elif IT == np.float32:
+            want = _np_pyrdown(imgs[l - 3], np.float32, lambda v: v * np.float32(1.0 / 256))
+        else:
+            want = _np_pyrdown(imgs[l - 3], np.float64, lambda v: v * (1.0 / 256))
+        assert imgs[l].shape == want.shape and np.array_equal(imgs[l], want), l
+    im8 = synth.synthetic_frame(9, 61, 77, 3)
+    a, _ = oracle.pyramid_images(im8, 4, 3)
+    b, _ = oracle.pyramid_images(im8.astype(np.uint16), 4, 3)
+    for l in range(3, len(a)):              # the integer pyrDown is the same formula; (resized levels use float for 16U)
+        if l % 3 == 0:
+            assert np.array_equal(a[l], b[l].astype(np.uint8)) and b[l].max() < 256
+
+
+def test_float_resize_against_numpy(oracle):
+    """INTER_LINEAR on float pixels: dst = (S00*a0 + S01*a1)*b0 + (S10*a0 + S11*a1)*b1 with float coefficients
+    (1-fx, fx), (1-fy, fy) of the same coordinate mapping as the 8-bit path."""
+    rng = np.random.default_rng(4)
+    src = (rng.random((37, 53, 1)) * 255).astype(np.float32)
+    imgs, _ = oracle.pyramid_images(src, 4, 2)
+    dst = imgs[1]
+    dr, dc = dst.shape[:2]
+    sr, sc = 37, 53
+    want = np.zeros((dr, dc), np.float32)
+    for dy in range(dr):
+        fy = np.float32((dy + 0.5) * (1.0 / (dr / sr)) - 0.5)
+        sy = int(np.floor(fy)); fy = np.float32(fy - np.float32(sy))
+        y0, y1 = min(max(sy, 0), sr - 1), min(max(sy + 1, 0), sr - 1)
+        b0, b1 = np.float32(1) - fy, fy
+        for dx in range(dc):
+            fx = np.float32((dx + 0.5) * (1.0 / (dc / sc)) - 0.5)
+            sx = int(np.floor(fx)); fx = np.float32(fx - np.float32(sx))
+            if sx < 0:
+                fx, sx = np.float32(0), 0
+            if sx >= sc - 1:
+                r0, r1 = src[y0, sc - 1, 0], src[y1, sc - 1, 0]
+            else:
+                a0, a1 = np.float32(1) - fx, fx
+                r0 = np.float32(src[y0, sx, 0] * a0) + np.float32(src[y0, sx + 1, 0] * a1)
+                r1 = np.float32(src[y1, sx, 0] * a0) + np.float32(src[y1, sx + 1, 0] * a1)
+            want[dy, dx] = np.float32(r0 * b0) + np.float32(r1 * b1)
+    assert np.array_equal(dst[:, :, 0], want)
