@@ -115,9 +115,10 @@ public:
             pyrafeatures[l].create(fr[l], fc[l] * 32, CV_32F);      // Mat(H, W*flen), src/HOGFeatures.cpp:180
             ptrs[l] = pyrafeatures[l].ptr<float>(0);
         }
-        // depth code 0 = CV_8U; other depths -> PBD_ERR_UNSUPPORTED (the reference's default: branch, :141-145)
-        check(h_, pbd_features_pyramid(h_, im.data, im.rows, im.cols, im.channels(), im.step, im.depth() == CV_8U ? 0 : im.depth(),
-                                       ptrs.data()));
+        // the depth codes of the C ABI are cv::Mat::depth() itself: CV_8U / CV_16U / CV_32F / CV_64F are the four
+        // features<IT> instantiations (src/HOGFeatures.cpp:136-146); any other depth -> PBD_ERR_UNSUPPORTED (the
+        // reference's default: branch, :141-145)
+        check(h_, pbd_features_pyramid(h_, im.data, im.rows, im.cols, im.channels(), im.step, im.depth(), ptrs.data()));
         scales_.assign(sc, sc + n);
     }
 };
@@ -168,7 +169,7 @@ inline void hipDetect(pbd_handle *h, const cv::Mat &im, vectorCandidate &candida
     const int stride = pbd_candidate_stride(h), cap = 1 << 16;
     std::vector<int32_t> buf((size_t)cap * stride);
     int n = 0;
-    check(h, pbd_detect(h, im.data, im.rows, im.cols, im.channels(), im.step, buf.data(), cap, &n));
+    check(h, pbd_detect_typed(h, im.data, im.rows, im.cols, im.channels(), im.step, im.depth(), buf.data(), cap, &n));
     for (int i = 0; i < n; ++i) {
         const int32_t *r = &buf[(size_t)i * stride];
         const pbd_candidate_hdr *hd = reinterpret_cast<const pbd_candidate_hdr *>(r);

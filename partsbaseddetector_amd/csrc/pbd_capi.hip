@@ -568,8 +568,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
     if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16) {
         if (!fast) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA / PBD_CONV_MFMA_F16 need 5x5 filters and PBD_REAL_F32");
         const bool f16 = h->cfg.conv_mode == PBD_CONV_MFMA_F16;
-        // records [pass][tap][160 filters][hi 32 bf16 | lo 32 bf16 | 8 pad], x = hi + lo with round-to-nearest-even;
-        // fp16 mode: [pass][tap][160 filters][32 fp16 | 8 pad]
+        // bf16 mode: x = hi + lo with round-to-nearest-even; fp16 mode: one rounding
         auto f2bf = [](float f) -> uint16_t {
             uint32_t u; memcpy(&u, &f, 4);
             if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
@@ -593,22 +592,28 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
             const uint32_t bits = e >= -14 ? (((uint32_t)(e + 15) << 10) + (q - 0x400u)) : q;   // carry propagates into the exponent
             return (uint16_t)(sign | bits);
         };
-        const int recw = (f16 ? kMfmaRecBytesF16 : kMfmaRecBytes) / 2;
+        // A-operand fragments in the order the kernel consumes them: [pass][tap][k-step][M-tile][hi|lo][lane] x 8 values.
+        // Lane (r = lane & 31, hh = lane >> 5) of v_mfma_f32_32x32x16 holds row r (filter), k = hh*8 .. hh*8+7 (channels)
+        const int NV = f16 ? 1 : 2, MT = kMfmaFilterBlock / 32;
         const int passes = (nfilters + kMfmaFilterBlock - 1) / kMfmaFilterBlock;
-        std::vector<uint16_t> rec((size_t)passes * K * K * kMfmaFilterBlock * recw, 0);
-        for (int f = 0; f < nfilters; ++f) {
-            const float *src = reinterpret_cast<const float *>(filters[f]);
-            for (int t = 0; t < K * K; ++t) {
-                uint16_t *r = &rec[(((size_t)(f / kMfmaFilterBlock) * K * K + t) * kMfmaFilterBlock + f % kMfmaFilterBlock) * recw];
-                for (int c = 0; c < 32; ++c) {
-                    const float v = src[(size_t)t * 32 + c];
-                    if (f16) { r[c] = f2h(v); continue; }
-                    const uint16_t hi = f2bf(v);
-                    r[c] = hi;
-                    r[32 + c] = f2bf(v - bf2f(hi));
-                }
-            }
-        }
+        std::vector<uint16_t> rec((size_t)passes * K * K * 2 * MT * NV * 64 * 8, 0);
+        for (int ps = 0; ps < passes; ++ps)
+            for (int t = 0; t < K * K; ++t)
+                for (int kh = 0; kh < 2; ++kh)
+                    for (int mt = 0; mt < MT; ++mt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int f = ps * kMfmaFilterBlock + mt * 32 + (lane & 31);
+                            if (f >= nfilters) continue;
+                            const float *src = reinterpret_cast<const float *>(filters[f]) + (size_t)t * 32 + kh * 16 + (lane >> 5) * 8;
+                            const size_t base = (((((size_t)ps * K * K + t) * 2 + kh) * MT + mt) * NV) * 64 * 8;
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = src[j];
+                                if (f16) { rec[base + (size_t)lane * 8 + j] = f2h(v); continue; }
+                                const uint16_t hi = f2bf(v);
+                                rec[base + (size_t)lane * 8 + j] = hi;
+                                rec[base + (size_t)(64 + lane) * 8 + j] = f2bf(v - bf2f(hi));
+                            }
+                        }
         HIPCHK(h, h->d_wrec.ensure(rec.size() * 2));
         HIPCHK(h, hipMemcpy(h->d_wrec.p, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
     }
@@ -1186,7 +1191,7 @@ extern "C" {
 const char *pbd_version(void) { return "pbd-hip 0.1 (gfx950)"; }
 
 // diagnostics, not part of include/pbd.h
-int pbd_debug_conv_occupancy(int nw) { return conv_occupancy(nw); }
+int pbd_debug_conv_occupancy(int nw) { return nw == 5 ? conv_mfma_occupancy(false) : nw == 6 ? conv_mfma_occupancy(true) : conv_occupancy(nw); }
 // the convolution's tile cover of one rows x cols level (host-only, no GPU needed): out[i] = {shape, y0, x0}
 int pbd_debug_cover_level(int rows, int cols, int *out, int capacity)
 {

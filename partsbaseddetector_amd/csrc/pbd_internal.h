@@ -210,6 +210,7 @@ void launch_hog_hist(const HogParams &p, int nframes, bool f64, hipStream_t s);
 void launch_hog_feat(const HogParams &p, int nframes, bool f64, hipStream_t s);
 void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s);
 int conv_occupancy(int nw);
+int conv_mfma_occupancy(bool f16);
 // matrix-core path (pbd_kernels_conv_mfma.hip); wrec: [pass][tap][160 filters][144 B] bf16 hi/lo records
 // PBD_CONV_MFMA_F16: 80 B fp16 records, one MFMA per product tile
 void launch_conv_mfma(const ConvParams &p, const void *wrec, bool f16, int nframes, hipStream_t s);

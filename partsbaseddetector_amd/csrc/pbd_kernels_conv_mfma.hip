@@ -10,17 +10,12 @@
 // hi*hi + hi*lo + lo*hi is accumulated in fp32 by v_mfma_f32_32x32x16_bf16: 16 significant bits per
 // operand, relative product error ~2^-16, three MFMAs per fp32 MAC tile instead of one.
 //
-// Mapping: workgroup = 32 x 8 pixel tile of one level/frame x 160 filters; 4 waves, each two pixel rows.
-//   A operand (M = 32 filters): weights of one tap, from LDS  [filter][hi 32ch | lo 32ch | pad]  (144 B)
-//   B operand (N = 32 pixels along x): features, from the LDS tile [cell][hi 32ch | lo 32ch | pad] (144 B)
-//   the 144-byte record stride makes the 16-byte fragment reads of 32 consecutive records bank-conflict free;
-//   D[filter][pixel]: lanes = pixels, registers = filters -> each store instruction writes 32 consecutive x.
-// The weights of tap t+1 are fetched from HBM/L2 into registers while tap t is computed.
+// Mapping: see conv_mfma_tile below.
 //
 // PBD_CONV_MFMA_F16 (BASELINE.json configs[4], SURVEY.md section 8(d) "Config 5"): the same contraction with
 // every operand rounded once to fp16 and ONE v_mfma_f32_32x32x16_f16 per product tile, fp32 accumulation.
 // Records are 80 bytes (32 fp16 + 16 pad, again conflict-free for the 16-byte fragment reads), a third of
-// the matrix-core work and 47 KB of LDS per workgroup (three resident workgroups per CU instead of one).
+// the matrix-core work and 35 KB of LDS per workgroup.
 // The 1e-4 score bar does NOT hold in this mode; tests report the error and the detection agreement.
 #include "pbd_internal.h"
 
@@ -33,20 +28,27 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaFB = 160;           // filters per pass (5 M-tiles of 32)
 
-template <int K, bool F16>
-__global__ __launch_bounds__(256) void k_conv_mfma(ConvParams p, const unsigned char *__restrict__ wrec,
-                                                   const float *__restrict__ featp, float *__restrict__ respp)
+// Workgroup = one 256-pixel tile (32 x 8, 16 x 16 or 8 x 32: the mixed cover of the exact kernel) of one level / frame
+// x 160 filters, FIVE waves: wave m owns the 32 filters of M-tile m and all 8 N-tiles (32 pixels each) of the tile.
+//   A operand (weights of one tap, 16 channels): straight from global memory / L2 in fragment order
+//     ([pass][tap][k-step][M-tile][hi|lo][lane] x 16 bytes, built once on the host) -- one coalesced 1 KB load per
+//     fragment, fetched one step ahead; every wave of every workgroup reads the same 800 KB, so they stay in L2 / L1.
+//   B operand (features): the haloed tile sits in LDS as [cell][hi 32ch | lo 32ch | pad] records (144 B, or 80 B for
+//     fp16: the 16-byte fragment reads of 32 consecutive cells are bank-conflict free), converted once per workgroup.
+//   No barrier after the tile is staged: the waves do not share anything else, so two workgroups per CU (62 KB of LDS
+//   each) keep the matrix pipes busy while others stage or store.
+//   D[filter][pixel]: lanes = pixels, registers = filters -> a store instruction writes runs of consecutive x.
+template <bool F16> struct MfmaRec { static constexpr int kBytes = F16 ? kMfmaRecBytesF16 : kMfmaRecBytes; };
+
+template <int K, bool F16, int S>
+__device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 *__restrict__ wfrag, const float *__restrict__ featp,
+                                               float *__restrict__ respp, unsigned char *sm_f, int *next_item, const ConvTile tile)
 {
-    constexpr int kRec = F16 ? kMfmaRecBytesF16 : kMfmaRecBytes;   // bytes per LDS record: 64 hi + 64 lo + 16 pad | 64 fp16 + 16 pad
-    constexpr int kRecU4 = kRec / 16;                              // 16-byte chunks per record
-    constexpr int TW = kConvTW, TH = kConvTH;
+    constexpr int kRec = MfmaRec<F16>::kBytes;
+    constexpr int TW = kConvTW >> S, TH = kConvTH << S;
     constexpr int PW = TW + K - 1, PH = TH + K - 1;
     constexpr int NCELL = PW * PH;
-    constexpr int MT = kMfmaFB / 32;
-    __shared__ __attribute__((aligned(16))) unsigned char sm_f[NCELL * kRec];
-    __shared__ __attribute__((aligned(16))) unsigned char sm_w[kMfmaFB * kRec];
-
-    const ConvTile tile = p.tiles[blockIdx.x];
+    constexpr int MT = kMfmaFB / 32, NT = 8, NV = F16 ? 1 : 2;
     const int frame = p.frame0 + blockIdx.z;
     const int pass = blockIdx.y;                       // block of 160 filters
     const LevelDesc d = p.lv[tile.level];
@@ -55,144 +57,188 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvParams p, const unsigned 
     const int t = threadIdx.x;
     const float *feat = featp + ((size_t)frame * p.cell_per_frame + d.cell_off) * 32;
 
-    // ---- stage the feature tile: fp32 -> (hi, lo) bf16; thread = (cell, 8-channel group)
-    for (int idx = t; idx < NCELL * 4; idx += 256) {
-        const int ci = idx >> 2, cg = idx & 3;
-        const int cy = ci / PW, cx = ci - cy * PW;
-        const int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
-        float v[8];
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float4 *src = reinterpret_cast<const float4 *>(feat + ((size_t)gy * W + gx) * 32 + cg * 8);
-            const float4 v0 = src[0], v1 = src[1];
-            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-        } else {
+    // ---- stage the feature tile: fp32 -> (hi, lo) bf16 or fp16; thread = (cell, 8-channel group); the loads of a
+    // batch of UB tasks are issued together (one exposed memory latency per batch instead of one per task)
+    {
+        constexpr int NTASK = NCELL * 4, NTHR = 256, UB = 4;
+        for (int base = 0; base < NTASK; base += NTHR * UB) {
+            float4 va[UB], vb[UB];
+            bool inside[UB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-            if (cg == 3) v[7] = 1.0f;                  // constant border: 1 on channel 31 (SpatialConvolutionEngine.cpp:153-156)
-        }
-        if constexpr (F16) {
-            f16x8 hv;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hv[j] = (_Float16)v[j];
-            *reinterpret_cast<f16x8 *>(sm_f + ci * kRec + cg * 16) = hv;
-        } else {
-            bf16x8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                hi[j] = (__bf16)v[j];
-                lo[j] = (__bf16)(v[j] - (float)hi[j]);
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * NTHR + t;
+                const int ci = idx >> 2, cg = idx & 3;
+                const int cy = ci / PW, cx = ci - cy * PW;
+                const int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
+                inside[u] = idx < NTASK && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                va[u] = vb[u] = float4{0.f, 0.f, 0.f, 0.f};
+                if (inside[u]) {
+                    const float4 *src = reinterpret_cast<const float4 *>(feat + ((size_t)gy * W + gx) * 32 + cg * 8);
+                    va[u] = src[0]; vb[u] = src[1];
+                }
             }
-            *reinterpret_cast<bf16x8 *>(sm_f + ci * kRec + cg * 16) = hi;
-            *reinterpret_cast<bf16x8 *>(sm_f + ci * kRec + 64 + cg * 16) = lo;
-        }
-    }
-
-    const int lane = t & 63, wave = t >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    f32x16 acc[MT][2];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * NTHR + t;
+                if (idx >= NTASK) continue;
+                const int ci = idx >> 2, cg = idx & 3;
+                float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+                if (!inside[u] && cg == 3) v[7] = 1.0f;        // constant border: 1 on channel 31 (SpatialConvolutionEngine.cpp:153-156)
+                if constexpr (F16) {
+                    f16x8 hv;
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+                    for (int j = 0; j < 8; ++j) hv[j] = (_Float16)v[j];
+                    *reinterpret_cast<f16x8 *>(sm_f + ci * kRec + cg * 16) = hv;
+                } else {
+                    bf16x8 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
-
-    // weights: [pass][tap][160 filters][kRec B]; one tap = 160*9 = 1440 (fp16: 800) 16-byte chunks, NQ per thread (last partial)
-    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(wrec) + (size_t)pass * (K * K) * (kMfmaFB * kRecU4);
-    constexpr int WCH = kMfmaFB * kRecU4;
-    constexpr int NQ = (WCH + 255) / 256;
-    u32x4 wreg[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int ch = t + q * 256;
-        wreg[q] = ch < WCH ? wsrc[ch] : u32x4{0, 0, 0, 0};
-    }
-    for (int tp = 0; tp < K * K; ++tp) {
-        __syncthreads();                               // previous tap's fragment reads are done (and the tile is staged)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int ch = t + q * 256;
-            if (ch < WCH) reinterpret_cast<u32x4 *>(sm_w)[ch] = wreg[q];
-        }
-        __syncthreads();
-        if (tp + 1 < K * K) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int ch = t + q * 256;
-                if (ch < WCH) wreg[q] = wsrc[(size_t)(tp + 1) * WCH + ch];
-            }
-        }
-        const int ti = tp / K, tj = tp - ti * K;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {               // two k-steps of 16 channels
-            const int coff = kh * 32 + hh * 16;        // byte offset of this lane's 8 channels inside the hi (or lo) half
-            if constexpr (F16) {
-                f16x8 bf[2];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int cell = (wave * 2 + n + ti) * PW + (r + tj);
-                    bf[n] = *reinterpret_cast<const f16x8 *>(sm_f + cell * kRec + coff);
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const f16x8 af = *reinterpret_cast<const f16x8 *>(sm_w + (m * 32 + r) * kRec + coff);
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[n], acc[m][n], 0, 0, 0);
-                }
-            } else {
-                bf16x8 bh[2], bl[2];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int cell = (wave * 2 + n + ti) * PW + (r + tj);
-                    bh[n] = *reinterpret_cast<const bf16x8 *>(sm_f + cell * kRec + coff);
-                    bl[n] = *reinterpret_cast<const bf16x8 *>(sm_f + cell * kRec + 64 + coff);
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sm_w + (m * 32 + r) * kRec + coff);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sm_w + (m * 32 + r) * kRec + 64 + coff);
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+                    for (int j = 0; j < 8; ++j) {
+                        hi[j] = (__bf16)v[j];
+                        lo[j] = (__bf16)(v[j] - (float)hi[j]);
                     }
+                    *reinterpret_cast<bf16x8 *>(sm_f + ci * kRec + cg * 16) = hi;
+                    *reinterpret_cast<bf16x8 *>(sm_f + ci * kRec + 64 + cg * 16) = lo;
                 }
             }
         }
     }
+    if (t == 0) *next_item = 0;
+    __syncthreads();
 
-    // D layout (32x32): column = lane & 31 (pixel), row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) (filter)
-    const int x = tile.x0 + r;
+    const int lane = t & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    // pixel q = n * 32 + r of the tile -> (py, px) = (q / TW, q % TW); byte offset of its cell record in the haloed LDS
+    // tile: N-tile n starts (32 / TW) rows below N-tile n - 1, so the offsets are cell0 + n * kNStep
+    const int cell0 = ((r / TW) * PW + (r % TW)) * kRec + hh * 16;
+    constexpr int kNStep = (32 / TW) * PW * kRec;
+    constexpr size_t kStep = (size_t)MT * NV * 64;
+    constexpr int NSTEP = K * K * 2;
     const size_t HW = (size_t)H * W;
     float *resp = respp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
-    if (x < W) {
+
+    // The 8 N-tiles are done in two halves of 4 (64 accumulator registers instead of 128): with ~110 registers per
+    // lane four waves fit a SIMD, so two or three 5-wave workgroups share a CU and one's matrix work covers the
+    // others' staging and stores.  The weights are streamed twice (from L2).
+    constexpr int NH = NT / 2;
+    // work item = (M-tile, half): 10 of them, handed out to the workgroup's FOUR waves through an LDS counter (five
+    // waves per workgroup would leave one SIMD with two: the second resident workgroup then rarely finds room)
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(next_item, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= MT * 2) break;
+        const int m = item >> 1, half = item & 1;
+        if (pass * kMfmaFB + m * 32 >= p.F) continue;              // no filters in this M-tile
+        // fragment stream of this M-tile: step s = tap * 2 + k-step; [s][m][v][lane]
+        const u32x4 *wsrc = wfrag + ((size_t)pass * (K * K * 2) * MT + m) * NV * 64 + lane;
+        const int f0 = pass * kMfmaFB + m * 32 + 4 * hh;
+        const int cellh = cell0 + half * NH * kNStep;
+        f32x16 acc[NH];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int y = tile.y0 + wave * 2 + n;
-            if (y < H) {
+        for (int n = 0; n < NH; ++n)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+        // weight fragments PF steps ahead of their use (a ring of registers with static indices: the step loop runs in
+        // groups of PF): an L2 round trip is longer than the 4 (fp16) or 12 (bf16) MFMAs of one step
+        constexpr int PF = 5;
+        static_assert(NSTEP % (2 * PF) == 0, "the step loop runs in whole groups of 2 * PF");
+        u32x4 wq[PF][NV];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int f = pass * kMfmaFB + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        if (f < p.F) resp[(size_t)f * HW + (size_t)y * W + x] = acc[m][n][e];
+        for (int j = 0; j < PF; ++j)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) wq[j][v] = wsrc[(size_t)j * kStep + v * 64];
+        // B fragments (features, LDS) of step s+1 are read while the MFMAs of step s run: two register sets
+        auto b_addr = [&](int sidx) {
+            const int tp = sidx >> 1, kh = sidx & 1;
+            const int ti = tp / K, tj = tp - ti * K;
+            return sm_f + (ti * PW + tj) * kRec + kh * 32 + cellh;
+        };
+        u32x4 bq[2][NH][NV];
+        auto b_load = [&](int buf, int sidx) {
+            const unsigned char *bbase = b_addr(sidx);
+#pragma unroll
+            for (int n = 0; n < NH; ++n)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) bq[buf][n][v] = *reinterpret_cast<const u32x4 *>(bbase + n * kNStep + v * 64);
+        };
+        b_load(0, 0);
+        static_assert(PF % 2 == 1 || NSTEP % 2 == 0, "buffer parity is static inside a group of PF steps");
+#pragma unroll 1
+        for (int s0 = 0; s0 < NSTEP; s0 += 2 * PF) {
+#pragma unroll
+            for (int j = 0; j < 2 * PF; ++j) {
+                const int sidx = s0 + j;
+                b_load((j + 1) & 1, min(sidx + 1, NSTEP - 1));
+                const int wj = j % PF;
+                if constexpr (F16) {
+                    const f16x8 af = __builtin_bit_cast(f16x8, wq[wj][0]);
+#pragma unroll
+                    for (int n = 0; n < NH; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, bq[j & 1][n][0]), acc[n], 0, 0, 0);
+                } else {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wq[wj][0]), al = __builtin_bit_cast(bf16x8, wq[wj][1]);
+#pragma unroll
+                    for (int n = 0; n < NH; ++n) {
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[j & 1][n][0]), bl = __builtin_bit_cast(bf16x8, bq[j & 1][n][1]);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
                     }
+                }
+                const int snext = min(sidx + PF, NSTEP - 1);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) wq[wj][v] = wsrc[(size_t)snext * kStep + v * 64];
+            }
+        }
+        // D layout (32x32): column = lane & 31 (pixel), row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) (filter)
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+            const int q = (half * NH + n) * 32 + r;
+            const int y = tile.y0 + q / TW, x = tile.x0 + q % TW;
+            if (x < W && y < H) {
+                float *rp = resp + (size_t)y * W + x;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int f = f0 + (e & 3) + 8 * (e >> 2);
+                    if (f < p.F) rp[(size_t)f * HW] = acc[n][e];
+                }
             }
         }
     }
 }
 
+template <int K, bool F16>
+__global__ __launch_bounds__(256, F16 ? 4 : 3) void k_conv_mfma(ConvParams p, const u32x4 *__restrict__ wfrag,
+                                                                      const float *__restrict__ featp, float *__restrict__ respp)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sm_f[433 * MfmaRec<F16>::kBytes];
+    __shared__ int next_item;
+    const int b = blockIdx.x;
+    const ConvTile tile = p.shaped[b];
+    if (b < p.nshaped[0]) conv_mfma_tile<K, F16, 0>(p, wfrag, featp, respp, sm_f, &next_item, tile);
+    else if (b < p.nshaped[0] + p.nshaped[1]) conv_mfma_tile<K, F16, 1>(p, wfrag, featp, respp, sm_f, &next_item, tile);
+    else conv_mfma_tile<K, F16, 2>(p, wfrag, featp, respp, sm_f, &next_item, tile);
+}
+
+int conv_mfma_occupancy(bool f16)
+{   // resident workgroups per CU (diagnostics)
+    int n = -1;
+    if (f16) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma<5, true>, 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma<5, false>, 256, 0);
+    return n;
+}
+
 void launch_conv_mfma(const ConvParams &p, const void *wrec, bool f16, int nframes, hipStream_t s)
 {
-    if (p.ntiles == 0 || p.F == 0) return;
+    const int nt = p.nshaped[0] + p.nshaped[1] + p.nshaped[2];
+    if (nt == 0 || p.F == 0) return;
     const int passes = (p.F + kMfmaFB - 1) / kMfmaFB;
-    dim3 grid(p.ntiles, passes, nframes);
+    dim3 grid(nt, passes, nframes);
     if (f16)
-        hipLaunchKernelGGL((k_conv_mfma<5, true>), grid, dim3(256), 0, s, p, static_cast<const unsigned char *>(wrec),
+        hipLaunchKernelGGL((k_conv_mfma<5, true>), grid, dim3(256), 0, s, p, static_cast<const u32x4 *>(wrec),
                            static_cast<const float *>(p.feat), static_cast<float *>(p.resp));
     else
-        hipLaunchKernelGGL((k_conv_mfma<5, false>), grid, dim3(256), 0, s, p, static_cast<const unsigned char *>(wrec),
+        hipLaunchKernelGGL((k_conv_mfma<5, false>), grid, dim3(256), 0, s, p, static_cast<const u32x4 *>(wrec),
                            static_cast<const float *>(p.feat), static_cast<float *>(p.resp));
 }
 
