@@ -124,6 +124,13 @@ int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int
 /* the resampled level images of the last pbd_features_pyramid / pbd_detect call (for tests) */
 int pbd_get_pyramid_image(pbd_handle *h, int frame, int level, uint8_t *dst);
 
+/* Level sharding (new surface; the reference has no multi-device mode): pyramid levels are independent through HOG,
+ * convolution and the dynamic program (src/DynamicProgram.cpp:115-119 reads only scores[n] of the same level), so ONE
+ * frame can be split over `world` GPUs -- handle `rank` then computes only its share of the levels (longest-processing-
+ * time assignment over the level sizes, the same on every rank) and returns only their candidates; the union over the
+ * ranks is the full result.  pbd_pyramid_plan reports 0 x 0 feature maps for the levels of other ranks.  (1, 0..): off. */
+int pbd_set_level_shard(pbd_handle *h, int rank, int world);
+
 /* ---- IConvolutionEngine (include/IConvolutionEngine.hpp:44-68), SpatialConvolutionEngine. */
 /* setFilters(filters): filters[f] is ksize[f] x (ksize[f]*flen) values of T.  pbd_create already
  * installs the model's filters; this replaces them (src/SpatialConvolutionEngine.cpp:133-159). */

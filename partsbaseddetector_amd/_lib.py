@@ -27,7 +27,7 @@ KERNELS = ["k_resize", "k_pyrdown", "k_hog_hist", "k_hog_feat", "k_conv", "k_dt_
 # every symbol include/pbd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "pbd_create", "pbd_destroy", "pbd_last_error", "pbd_version", "pbd_candidate_stride", "pbd_binsize",
-    "pbd_pyramid_plan", "pbd_features_pyramid", "pbd_get_pyramid_image", "pbd_conv_set_filters", "pbd_conv_pdf",
+    "pbd_pyramid_plan", "pbd_set_level_shard", "pbd_features_pyramid", "pbd_get_pyramid_image", "pbd_conv_set_filters", "pbd_conv_pdf",
     "pbd_num_ptr_slots", "pbd_ptr_slot", "pbd_dp_min", "pbd_dp_argmin", "pbd_detect", "pbd_detect_batch",
     "pbd_detect_batch_device", "pbd_detect_typed", "pbd_detect_batch_submit", "pbd_detect_batch_wait", "pbd_get_stage", "pbd_profile_enable", "pbd_profile_reset", "pbd_profile_read",
     "pbd_kernel_name", "pbd_synchronize",
@@ -85,6 +85,7 @@ def load():
     for name in ("pbd_candidate_stride", "pbd_binsize", "pbd_num_ptr_slots", "pbd_synchronize", "pbd_profile_reset"):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.pbd_ptr_slot.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.pbd_set_level_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pbd_pyramid_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_float)]
     lib.pbd_features_pyramid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
                                          C.POINTER(C.c_void_p)]

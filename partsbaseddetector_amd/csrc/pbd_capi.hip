@@ -218,6 +218,7 @@ struct pbd_handle {
     Plan *cur = nullptr;
     int cur_frames = 0, cur_cn = 3;
     int cur_depth = kDepth8U;        // image depth of the frames being processed (set by the entry point)
+    int shard_rank = 0, shard_world = 1;   // level sharding of single frames over several GPUs (pbd_set_level_shard)
     bool have_features = false, have_resp = false, have_dp = false;
 
     // workspace
@@ -453,6 +454,33 @@ int get_image_plan(pbd_handle *h, int rows, int cols, Plan **out)
                 taby.push_back({y0, y1, sat_short_round((1.f - fy) * 2048), sat_short_round(fy * 2048)});
                 tabyf.push_back({y0, y1, 1.f - fy, fy});
             }
+        }
+    }
+    if (h->shard_world > 1) {
+        // Level sharding (secondary partitioning): levels are independent through HOG, convolution and DP, so
+        // one frame can be split over GPUs by giving each a subset of the levels.  Longest-processing-time assignment
+        // over the cell counts (level 0 alone is 13 % of a VGA frame): levels by decreasing size, each to the rank
+        // with the least work so far.  Levels of other ranks keep their pyramid image here (a pyrDown chain may run
+        // through them) but get empty block / feature maps, so every later stage skips them.
+        std::vector<int> order(n);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            return (long long)P->lv[a].rows * P->lv[a].cols > (long long)P->lv[b].rows * P->lv[b].cols;
+        });
+        std::vector<long long> load(h->shard_world, 0);
+        std::vector<int> owner(n, 0);
+        for (int l : order) {
+            const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            owner[l] = r;
+            load[r] += (long long)P->lv[l].rows * P->lv[l].cols;
+        }
+        blk = 0; cell = 0;
+        for (int l = 0; l < n; ++l) {
+            LevelDesc &d = P->lv[l];
+            if (owner[l] != h->shard_rank) d.blk_rows = d.blk_cols = d.rows = d.cols = 0;
+            d.blk_off = blk; d.cell_off = cell;
+            blk += (long long)d.blk_rows * d.blk_cols;
+            cell += (long long)d.rows * d.cols;
         }
     }
     P->pix_per_frame = pix; P->blk_per_frame = blk; P->cell_per_frame = cell;
@@ -1307,6 +1335,25 @@ int pbd_ptr_slot(const pbd_handle *h, int component, int part)
     const int p0 = h->part_offset[component];
     if (part < 0 || p0 + part >= h->part_offset[component + 1]) return -1;
     return h->ptr_slot[p0 + part];
+}
+
+int pbd_set_level_shard(pbd_handle *h, int rank, int world)
+{
+    return guarded(h, [&]() -> int {
+        if (!h) return PBD_ERR_INVALID;
+        if (world < 1 || rank < 0 || rank >= world) return fail(h, PBD_ERR_INVALID, "level shard %d of %d", rank, world);
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
+        if (rank == h->shard_rank && world == h->shard_world) return PBD_OK;
+        (void)hipSetDevice(h->cfg.device);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));
+        h->shard_rank = rank; h->shard_world = world;
+        // image plans depend on the shard
+        h->cur = nullptr; h->have_features = h->have_resp = h->have_dp = false;
+        for (size_t i = 0; i < h->plans.size();)
+            if (h->plans[i]->kind == 0) h->plans.erase(h->plans.begin() + i); else ++i;
+        return PBD_OK;
+    });
 }
 
 int pbd_pyramid_plan(pbd_handle *h, int rows, int cols, int *nlevels, int *img_rows, int *img_cols, int *feat_rows,

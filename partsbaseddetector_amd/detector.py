@@ -113,6 +113,10 @@ class Handle:
             raise PbdError(rc, self.lib.pbd_last_error(self.h).decode())
         return rc
 
+    def set_level_shard(self, rank: int, world: int) -> None:
+        """pbd_set_level_shard: this handle computes only its share of the pyramid levels of each frame"""
+        self.check(self.lib.pbd_set_level_shard(self.h, rank, world))
+
     # ---- helpers -------------------------------------------------------------------------------
     def plan(self, rows: int, cols: int):
         n = C.c_int()

@@ -147,3 +147,25 @@ def gather_candidates(buf: np.ndarray, n: int, stride: int, cap: int, frame_offs
     """One-shot form: every rank returns the concatenated (N, stride) records.  `cap` is only the initial
     capacity (see CandidateGatherer)."""
     return CandidateGatherer(stride, cap, device).gather(buf, n, frame_offset)
+
+
+def detect_level_sharded(det, im, gatherer: "CandidateGatherer", root_only: bool = False):
+    """ONE frame over all ranks (secondary partitioning): every rank holds the frame, computes its
+    share of the pyramid levels (`pbd_set_level_shard`: longest-processing-time assignment over the level sizes) and the
+    candidate lists are gathered with the usual single collective; the records come back sorted by
+    (frame, level, component, y, x) like a single-GPU call."""
+    det.hd.set_level_shard(gatherer.rank, gatherer.world)
+    cands = det.detect(im)
+    stride = det.hd.stride
+    buf = np.zeros(max(len(cands), 1) * stride, np.int32)
+    for i, c in enumerate(cands):
+        r = buf[i * stride:(i + 1) * stride]
+        r[0], r[1], r[2], r[3], r[4] = c.frame, c.component, c.level, c.root[0], c.root[1]
+        r[5:6] = np.float32(c.score()).view(np.int32)
+        r[6] = len(c.parts)
+        r[8:8 + 4 * len(c.parts)] = c.parts.ravel()
+    rec = gatherer.gather(buf, len(cands), frame_offset=0, root_only=root_only)
+    if rec is None:
+        return None
+    order = np.lexsort((rec[:, 3], rec[:, 4], rec[:, 1], rec[:, 2], rec[:, 0]))
+    return rec[order]

@@ -662,3 +662,37 @@ def test_image_depths_16u_32f_64f(det_mod, oracle, IT):
             det.distributeModel(model)
             _compare_candidates(det.detect(im), oracle.detect(model.flatten(), im, dtype=T))
             det.hd.close()
+
+
+def test_level_sharding_of_one_frame(det_mod, oracle):
+    """SURVEY 8(e) secondary partitioning: one frame split over `world` GPUs by pyramid level.  Rehearsed on one GPU:
+    the handle takes the role of every rank in turn; the union of the per-rank candidate lists is the full (oracle)
+    result, every level belongs to exactly one rank, and the longest-processing-time assignment balances the cell
+    counts (level 0 alone is 13 % of a VGA pyramid)."""
+    model = M.synthetic_person_model(thresh=18.3)
+    flat = model.flatten()
+    im = synth.synthetic_frame(3, 480, 640, 3)
+    want = oracle.detect(flat, im)
+    assert len(want) > 20
+    det = det_mod.PartsBasedDetector(device=0)
+    det.distributeModel(model)
+    full_plan = det.hd.plan(480, 640)
+    for world in (2, 4):
+        got, loads, owned = [], [], np.zeros(full_plan["nlevels"], np.int32)
+        for rank in range(world):
+            det.hd.set_level_shard(rank, world)
+            plan = det.hd.plan(480, 640)
+            cells = plan["feat_rows"].astype(np.int64) * plan["feat_cols"]
+            owned += (cells > 0)
+            loads.append(int(cells.sum()))
+            mine = det.detect(im)
+            assert all(cells[c.level] > 0 for c in mine)
+            got += mine
+        full_cells = full_plan["feat_rows"].astype(np.int64) * full_plan["feat_cols"]
+        assert np.array_equal(owned, (full_cells > 0).astype(np.int32))          # a partition of the levels
+        assert sum(loads) == int(full_cells.sum()) and max(loads) <= 1.1 * sum(loads) / world, loads
+        got.sort(key=lambda c: (c.level, c.component, c.root[1], c.root[0]))
+        _compare_candidates(got, want)
+    det.hd.set_level_shard(0, 1)
+    _compare_candidates(det.detect(im), want)
+    det.hd.close()
