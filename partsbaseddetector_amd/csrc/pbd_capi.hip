@@ -212,6 +212,8 @@ struct pbd_handle {
     int coord_n = 0;
     bool f64 = false;                // reference template parameter T = double
     size_t rs = sizeof(float);       // sizeof(T)
+    bool resp_half = false;          // PBD_CONV_MFMA_F16: the responses live on the device as fp16 (BASELINE configs[4])
+    size_t resp_es = sizeof(float);  // bytes per response element on the device
 
     // plans
     std::vector<std::unique_ptr<Plan>> plans;
@@ -552,6 +554,42 @@ int get_dims_plan(pbd_handle *h, int nlevels, const int *rows, const int *cols, 
     return PBD_OK;
 }
 
+// IEEE binary16 <-> float on the host (round to nearest even, what v_cvt_f16_f32 does)
+uint16_t host_f2h(float f)
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t ax = u & 0x7fffffffu;
+    if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                // rounds to >= 65520: inf
+    if (ax < 0x33000001u) return sign;                                       // below half the smallest subnormal: 0
+    const int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                              // bits dropped from the 24-bit significand
+    const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
+    uint32_t q = m >> shift;
+    if (rest > half || (rest == half && (q & 1u))) ++q;
+    const uint32_t bits = e >= -14 ? (((uint32_t)(e + 15) << 10) + (q - 0x400u)) : q;   // carry propagates into the exponent
+    return (uint16_t)(sign | bits);
+}
+float host_h2f(uint16_t hv)
+{
+    const uint32_t sign = (uint32_t)(hv & 0x8000u) << 16;
+    const uint32_t ex = (hv >> 10) & 0x1fu, man = hv & 0x3ffu;
+    uint32_t u;
+    if (ex == 0x1f) u = sign | 0x7f800000u | (man << 13);
+    else if (ex != 0) u = sign | ((ex + 112u) << 23) | (man << 13);
+    else if (man == 0) u = sign;
+    else {                                                                   // subnormal half: normalise
+        int sh = 0;
+        uint32_t mm = man;
+        while (!(mm & 0x400u)) { mm <<= 1; ++sh; }
+        u = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ffu) << 13);
+    }
+    float f; memcpy(&f, &u, 4);
+    return f;
+}
+
 // ---- model tables --------------------------------------------------------------------------------
 template <typename R>
 int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize)
@@ -604,22 +642,6 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
             return (uint16_t)(u >> 16);
         };
         auto bf2f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
-        auto f2h = [](float f) -> uint16_t {      // IEEE binary16, round to nearest even (what v_cvt_f16_f32 does)
-            uint32_t u; memcpy(&u, &f, 4);
-            const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
-            const uint32_t ax = u & 0x7fffffffu;
-            if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
-            if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                // rounds to >= 65520: inf
-            if (ax < 0x33000001u) return sign;                                       // below half the smallest subnormal: 0
-            const int e = (int)(ax >> 23) - 127;
-            uint32_t m = (ax & 0x7fffffu) | 0x800000u;
-            int shift = e >= -14 ? 13 : 13 + (-14 - e);                              // bits dropped from the 24-bit significand
-            const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
-            uint32_t q = m >> shift;
-            if (rest > half || (rest == half && (q & 1u))) ++q;
-            const uint32_t bits = e >= -14 ? (((uint32_t)(e + 15) << 10) + (q - 0x400u)) : q;   // carry propagates into the exponent
-            return (uint16_t)(sign | bits);
-        };
         // A-operand fragments in the order the kernel consumes them: [pass][tap][k-step][M-tile][hi|lo][lane] x 8 values.
         // Lane (r = lane & 31, hh = lane >> 5) of v_mfma_f32_32x32x16 holds row r (filter), k = hh*8 .. hh*8+7 (channels)
         const int NV = f16 ? 1 : 2, MT = kMfmaFilterBlock / 32;
@@ -636,7 +658,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
                             const size_t base = (((((size_t)ps * K * K + t) * 2 + kh) * MT + mt) * NV) * 64 * 8;
                             for (int j = 0; j < 8; ++j) {
                                 const float v = src[j];
-                                if (f16) { rec[base + (size_t)lane * 8 + j] = f2h(v); continue; }
+                                if (f16) { rec[base + (size_t)lane * 8 + j] = host_f2h(v); continue; }
                                 const uint16_t hi = f2bf(v);
                                 rec[base + (size_t)lane * 8 + j] = hi;
                                 rec[base + (size_t)(64 + lane) * 8 + j] = f2bf(v - bf2f(hi));
@@ -935,7 +957,7 @@ void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int cn, int f
 int alloc_conv(pbd_handle *h, Plan &P, int nframes)
 {
     if (!h->filters_set) return fail(h, PBD_ERR_STATE, "pdf() before setFilters()");
-    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * h->F * h->rs, 16)));
+    HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * h->F * h->resp_es, 16) + 32));   // + slack: 16-half chunk reads
     return PBD_OK;
 }
 
@@ -1003,7 +1025,7 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     DpParams dp{};
     dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC; dp.NM = h->NM;
     dp.cell_per_frame = P.cell_per_frame; dp.quad_per_frame = P.quad_per_frame; dp.max_mix = h->max_mix;
-    dp.resp = h->resp.p; dp.acc = h->acc.p;
+    dp.resp = h->resp.p; dp.resp_half = h->resp_half ? 1 : 0; dp.acc = h->acc.p;
     dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;
     dp.IxT = h->IxT.as<int16_t>(); dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
@@ -1269,6 +1291,8 @@ int pbd_create(const pbd_model *model, const pbd_config *config, pbd_handle **ou
         h->cfg = *config;
         h->f64 = config->real_type == PBD_REAL_F64;
         h->rs = h->f64 ? sizeof(double) : sizeof(float);
+        h->resp_half = config->conv_mode == PBD_CONV_MFMA_F16 && !h->f64;
+        h->resp_es = h->resp_half ? 2 : h->rs;
         if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
         if (h->cfg.max_candidates < 1) h->cfg.max_candidates = 65536;
         if (config->stream) {
@@ -1457,10 +1481,20 @@ int pbd_conv_pdf(pbd_handle *h, int nlevels, const void *const *feat, const int 
         }
         h->cur = P; h->cur_frames = 1; h->have_features = true; h->have_resp = h->have_dp = false;
         if ((rc = run_conv(h, *P, 1)) != PBD_OK) return rc;
+        std::vector<uint16_t> halfbuf;
         for (int l = 0; l < nlevels; ++l) {
             const size_t n = (size_t)rows[l] * cols[l] * h->F;
-            if (n) HIPCHK(h, hipMemcpyAsync(resp[l], h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->rs, n * h->rs,
-                                            hipMemcpyDeviceToHost, h->stream));
+            if (!n) continue;
+            const char *src = h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->resp_es;
+            if (h->resp_half) {      // fp16 on the device, T = float at the seam
+                halfbuf.resize(n);
+                HIPCHK(h, hipMemcpyAsync(halfbuf.data(), src, n * 2, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                float *dst = static_cast<float *>(resp[l]);
+                for (size_t i = 0; i < n; ++i) dst[i] = host_h2f(halfbuf[i]);
+            } else {
+                HIPCHK(h, hipMemcpyAsync(resp[l], src, n * h->rs, hipMemcpyDeviceToHost, h->stream));
+            }
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return PBD_OK;
@@ -1479,11 +1513,20 @@ int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, con
             return fail(h, PBD_ERR_STATE, "the filter bank set by setFilters() (%d filters) does not cover the model's filter ids", h->F);
         int rc = get_dims_plan(h, nlevels, rows, cols, &P);
         if (rc != PBD_OK) return rc;
-        HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)P->cell_per_frame * h->F * h->rs, 16)));
+        HIPCHK(h, h->resp.ensure(std::max<size_t>((size_t)P->cell_per_frame * h->F * h->resp_es, 16) + 32));
+        std::vector<uint16_t> halfbuf;
         for (int l = 0; l < nlevels; ++l) {
             const size_t n = (size_t)rows[l] * cols[l] * h->F;
-            if (n) HIPCHK(h, hipMemcpyAsync(h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->rs, resp[l], n * h->rs,
-                                            hipMemcpyHostToDevice, h->stream));
+            if (!n) continue;
+            char *dst = h->resp.as<char>() + (size_t)P->lv[l].cell_off * h->F * h->resp_es;
+            if (h->resp_half) {      // the device side of this mode reads fp16 responses (exact for what pbd_conv_pdf returned)
+                halfbuf.resize(n);
+                const float *src = static_cast<const float *>(resp[l]);
+                for (size_t i = 0; i < n; ++i) halfbuf[i] = host_f2h(src[i]);
+                HIPCHK(h, hipMemcpy(dst, halfbuf.data(), n * 2, hipMemcpyHostToDevice));
+            } else {
+                HIPCHK(h, hipMemcpyAsync(dst, resp[l], n * h->rs, hipMemcpyHostToDevice, h->stream));
+            }
         }
         h->cur = P; h->cur_frames = 1; h->have_resp = true; h->have_dp = false;
         if ((rc = run_dp(h, *P, 1)) != PBD_OK) return rc;
@@ -1678,7 +1721,7 @@ int pbd_get_stage(pbd_handle *h, int stage, int frame, int level, void *dst, siz
             src = h->feat.as<char>() + ((size_t)frame * cpf + d.cell_off) * 32 * h->rs; bytes = hw * 32 * h->rs; break;
         case PBD_STAGE_RESPONSES:
             if (!h->have_resp) return fail(h, PBD_ERR_STATE, "responses not computed");
-            src = h->resp.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->F * h->rs; bytes = hw * h->F * h->rs; break;
+            src = h->resp.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->F * h->resp_es; bytes = hw * h->F * h->rs; break;
         case PBD_STAGE_ROOTV:
             if (!h->have_dp) return fail(h, PBD_ERR_STATE, "dp not computed");
             src = h->rootv.as<char>() + ((size_t)frame * cpf + d.cell_off) * h->NC * h->rs; bytes = hw * h->NC * h->rs; break;
@@ -1688,6 +1731,15 @@ int pbd_get_stage(pbd_handle *h, int stage, int frame, int level, void *dst, siz
         default: return fail(h, PBD_ERR_INVALID, "unknown stage %d", stage);
         }
         if (dst_bytes < bytes) return fail(h, PBD_ERR_INVALID, "destination holds %zu bytes, need %zu", dst_bytes, bytes);
+        if (stage == PBD_STAGE_RESPONSES && h->resp_half && bytes) {     // fp16 on the device -> T = float
+            const size_t n = bytes / sizeof(float);
+            std::vector<uint16_t> halfbuf(n);
+            HIPCHK(h, hipMemcpyAsync(halfbuf.data(), src, n * 2, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            float *out = static_cast<float *>(dst);
+            for (size_t i = 0; i < n; ++i) out[i] = host_h2f(halfbuf[i]);
+            return PBD_OK;
+        }
         if (bytes) HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return PBD_OK;

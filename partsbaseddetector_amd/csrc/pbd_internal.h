@@ -149,7 +149,7 @@ struct ConvParams {
     long long cell_per_frame;
     const void *feat;             // R [frames][cell_per_frame*32]
     const void *wts;              // R; 5x5 float kernel: [group][32][tap][8]; generic: [32][k*k][Fpad]
-    void *resp;                   // R [frames][cell_per_frame*F], level-major then filter planes
+    void *resp;                   // R [frames][cell_per_frame*F], level-major then filter planes (fp16 in PBD_CONV_MFMA_F16 mode)
     int fma;
 };
 
@@ -159,7 +159,8 @@ struct DpParams {
     int F, NS, NC, NM;            // filters, pointer slots, components, (part, mixture) pairs
     long long cell_per_frame;
     int frame0;                   // first frame of this chunk (absolute index into resp/msg/ptr buffers)
-    const void *resp;             // R
+    const void *resp;             // R, or fp16 when resp_half (PBD_CONV_MFMA_F16: BASELINE configs[4] "fp16 responses")
+    int resp_half;
     void *acc;                    // R [frames][cell_per_frame*NM] accumulated scores of non-leaf parts
     int16_t *Ix, *Iy;             // [frames][cell_per_frame*NS]
     uint8_t *Ik;

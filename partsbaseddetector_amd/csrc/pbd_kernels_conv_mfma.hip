@@ -196,11 +196,20 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 
             const int q = (half * NH + n) * 32 + r;
             const int y = tile.y0 + q / TW, x = tile.x0 + q % TW;
             if (x < W && y < H) {
-                float *rp = resp + (size_t)y * W + x;
+                if constexpr (F16) {       // fp16 responses (BASELINE configs[4]): same element index, half the bytes
+                    _Float16 *rp = reinterpret_cast<_Float16 *>(respp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)y * W + x;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int f = f0 + (e & 3) + 8 * (e >> 2);
-                    if (f < p.F) rp[(size_t)f * HW] = acc[n][e];
+                    for (int e = 0; e < 16; ++e) {
+                        const int f = f0 + (e & 3) + 8 * (e >> 2);
+                        if (f < p.F) rp[(size_t)f * HW] = (_Float16)acc[n][e];
+                    }
+                } else {
+                    float *rp = resp + (size_t)y * W + x;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int f = f0 + (e & 3) + 8 * (e >> 2);
+                        if (f < p.F) rp[(size_t)f * HW] = acc[n][e];
+                    }
                 }
             }
         }

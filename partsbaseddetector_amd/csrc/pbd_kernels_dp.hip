@@ -187,10 +187,12 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
 
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef short v8s_u __attribute__((ext_vector_type(8), aligned(2)));
+typedef _Float16 v8h_u __attribute__((ext_vector_type(8), aligned(2)));
 static_assert(kDtCH % 8 == 0, "the columns pass reads its int16 pointers 8 at a time");
 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
-template <typename R>
+// RH: the responses are fp16 (PBD_CONV_MFMA_F16); a template parameter so that the default kernels carry none of it
+template <typename R, bool RH>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
@@ -210,6 +212,10 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const R *src = (job.from_acc ? static_cast<const R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM
                                  : static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F) +
                    (size_t)job.plane * HW + (size_t)y * W;
+    // fp16 responses (PBD_CONV_MFMA_F16): a leaf part's input is read as halves, same element index
+    const bool hsrc = RH && !job.from_acc;
+    const _Float16 *srch = static_cast<const _Float16 *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F +
+                           (size_t)job.plane * HW + (size_t)y * W;
     // outputs go out TRANSPOSED ([x][y]): lanes are adjacent rows y, so every store instruction writes
     // whole lines; the columns pass reads its own column back with wide per-lane loads
     const int Hl = d.rows;
@@ -223,7 +229,19 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const int N = active ? W : 0;
     if (N == 0) return;
     auto load = [&](int q0, R *buf) {
-        if (sizeof(R) == 4 && q0 + kDtCH <= N) {
+        if (hsrc) {
+            if (q0 + kDtCH <= N) {
+#pragma unroll
+                for (int v = 0; v < kDtCH / 8; ++v) {
+                    const v8h_u a0 = *reinterpret_cast<const v8h_u *>(srch + q0 + 8 * v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) buf[8 * v + e] = (R)(float)a0[e];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < N) ? (R)(float)srch[q0 + i] : (R)0;
+            }
+        } else if (sizeof(R) == 4 && q0 + kDtCH <= N) {
             const float *srcf = reinterpret_cast<const float *>(src);
 #pragma unroll
             for (int v = 0; v < kDtCH / 4; ++v) {
@@ -249,8 +267,9 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
     if (p.JG == 0 || p.nrows_flat == 0) return;
     const int nwv = (p.nrows_flat + 63) / 64;
     dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
-    if (f64) hipLaunchKernelGGL(k_dt_rows<double>, grid, dim3(64 * kDtWaves), 0, s, p);
-    else hipLaunchKernelGGL(k_dt_rows<float>, grid, dim3(64 * kDtWaves), 0, s, p);
+    if (f64) hipLaunchKernelGGL((k_dt_rows<double, false>), grid, dim3(64 * kDtWaves), 0, s, p);
+    else if (p.resp_half) hipLaunchKernelGGL((k_dt_rows<float, true>), grid, dim3(64 * kDtWaves), 0, s, p);
+    else hipLaunchKernelGGL((k_dt_rows<float, false>), grid, dim3(64 * kDtWaves), 0, s, p);
 }
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
@@ -335,6 +354,7 @@ template <typename T, int N> struct CellVec;
 #define PBD_CELLVEC(T, E, N) template <> struct CellVec<T, N> { typedef E type __attribute__((ext_vector_type(N), aligned(sizeof(E)))); }
 PBD_CELLVEC(float, float, 4); PBD_CELLVEC(float, float, 2); PBD_CELLVEC(double, double, 4); PBD_CELLVEC(double, double, 2);
 PBD_CELLVEC(int16_t, short, 4); PBD_CELLVEC(int16_t, short, 2); PBD_CELLVEC(uint8_t, unsigned char, 4); PBD_CELLVEC(uint8_t, unsigned char, 2);
+PBD_CELLVEC(_Float16, _Float16, 4); PBD_CELLVEC(_Float16, _Float16, 2);
 #undef PBD_CELLVEC
 
 template <typename T, int kCpt>
@@ -364,7 +384,7 @@ __device__ __forceinline__ void store_cells(T *dst, int n, const T *src)
 }
 
 // MAXM: compile-time bound on the mixtures per part of the model (register arrays are sized by it)
-template <typename R, int kCpt, int MAXM>
+template <typename R, int kCpt, int MAXM, bool RH>
 __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
 {
     constexpr int SUB = 4 / kCpt;   // threads per group of 4 cells
@@ -394,7 +414,17 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
     for (int pm = 0; pm < MAXM; ++pm) {
 #pragma unroll
         for (int e = 0; e < kCpt; ++e) accv[pm][e] = (R)0;
-        if (pm < cj.npar) load_cells<R, kCpt>(resp + (size_t)cj.filter[pm] * HW, n, accv[pm]);
+        if (pm < cj.npar) {
+            if constexpr (RH) {
+                _Float16 hv[kCpt];
+                load_cells<_Float16, kCpt>(reinterpret_cast<const _Float16 *>(p.resp) +
+                                               ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + local + (size_t)cj.filter[pm] * HW, n, hv);
+#pragma unroll
+                for (int e = 0; e < kCpt; ++e) accv[pm][e] = (R)(float)hv[e];
+            } else {
+                load_cells<R, kCpt>(resp + (size_t)cj.filter[pm] * HW, n, accv[pm]);
+            }
+        }
     }
     // the job tables and biases are read-only and wave-uniform: reading them through the constant address
     // space keeps them on the scalar unit (a plain global load after the first store would be a vector load
@@ -473,8 +503,9 @@ void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hip
     const dim3 g2((unsigned)((p.quad_per_frame * 2 + 255) / 256), ncjobs, nframes), g4((unsigned)((p.quad_per_frame + 255) / 256), ncjobs, nframes);
 #define PBD_COMBINE(M)                                                                      \
     do {                                                                                    \
-        if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2, M>), g2, dim3(256), 0, s, p);   \
-        else hipLaunchKernelGGL((k_dp_combine<float, 4, M>), g4, dim3(256), 0, s, p);        \
+        if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2, M, false>), g2, dim3(256), 0, s, p);   \
+        else if (p.resp_half) hipLaunchKernelGGL((k_dp_combine<float, 4, M, true>), g4, dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((k_dp_combine<float, 4, M, false>), g4, dim3(256), 0, s, p);        \
     } while (0)
     if (p.max_mix <= 2) PBD_COMBINE(2);
     else if (p.max_mix <= 4) PBD_COMBINE(4);
@@ -529,7 +560,10 @@ __global__ __launch_bounds__(256) void k_dp_combine_seq(DpParams p)
         const size_t o = pbase + (size_t)(sj.slot + pm) * HW;
         p.Ix[o] = (int16_t)ix; p.Iy[o] = (int16_t)iy; p.Ik[o] = (uint8_t)bi;
         R *t = accp + (size_t)sj.target[pm] * HW;
-        const R base = sj.init[pm] ? respp[(size_t)sj.filter[pm] * HW] : *t;
+        const R base = !sj.init[pm] ? *t
+                       : (sizeof(R) == 4 && p.resp_half)
+                             ? (R)(float)(reinterpret_cast<const _Float16 *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + local)[(size_t)sj.filter[pm] * HW]
+                             : respp[(size_t)sj.filter[pm] * HW];
         *t = base + best;
     }
 }
@@ -557,14 +591,20 @@ __global__ __launch_bounds__(256) void k_dp_root(DpParams p)
     const size_t HW = (size_t)d.rows * d.cols;
     const R *accp = static_cast<const R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM;
     const R *respp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
+    const _Float16 *resph = static_cast<const _Float16 *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
+    const bool rh = sizeof(R) == 4 && p.resp_half;
+    auto score = [&](int mm) -> R {
+        const size_t o = (size_t)rj.plane[mm] * HW + local;
+        return ((rj.from_acc >> mm) & 1) ? accp[o] : rh ? (R)(float)resph[o] : respp[o];
+    };
     R best;
     int bi = 0;
     if (rj.nmix == 1) {
-        best = ((rj.from_acc & 1) ? accp : respp)[(size_t)rj.plane[0] * HW + local] + (R)rj.bias;
+        best = score(0) + (R)rj.bias;
     } else {
         best = -RealLimits<R>::inf();
         for (int mm = 0; mm < rj.nmix; ++mm) {
-            const R wv = (((rj.from_acc >> mm) & 1) ? accp : respp)[(size_t)rj.plane[mm] * HW + local] + (R)rj.bias;
+            const R wv = score(mm) + (R)rj.bias;
             if (wv > best) { bi = mm; best = wv; }
         }
     }

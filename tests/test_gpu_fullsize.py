@@ -123,7 +123,9 @@ def test_config4_mfma_f16_one_vga_frame(oracle, vga_batch):
             for l in (0, 10, 25, len(feats) - 1):
                 H, W = feats[l].shape[0], feats[l].shape[1] // 32
                 r = det.hd.get_stage(_lib.STAGE_RESPONSES, 0, l, H, W)
-                worst = max(worst, float(np.abs(r - oracle.responses(flat, feats[l])).max()))
+                ref = oracle.responses(flat, feats[l])
+                worst = max(worst, float(np.abs(r - ref).max()))
+                assert np.all(np.abs(r - ref) <= 2e-3 + 2.0 ** -10 * np.abs(ref))       # fp16 operands + fp16 responses
         det.hd.close()
     common = set(res["exact"]) & set(res["f16"])
     same = sum(np.array_equal(res["exact"][k].parts, res["f16"][k].parts) for k in common)
@@ -131,6 +133,6 @@ def test_config4_mfma_f16_one_vga_frame(oracle, vga_batch):
     print(f"configs[4] VGA: max |response - reference| = {worst:.3g}; roots exact {len(res['exact'])}, fp16 {len(res['f16'])}, "
           f"common {len(common)}, identical part placements {same}, max score diff {dscore:.3g}")
     assert len(res["exact"]) > 0
-    assert worst <= 5e-3
+    assert worst <= 1e-2
     assert len(common) >= 0.9 * max(len(res["exact"]), len(res["f16"]))
     assert same >= 0.5 * len(common)      # part placements move on near ties at fp16 precision: the rate is the reported figure
