@@ -140,3 +140,27 @@ def test_demo_nms_matches_python_mirror(demo, tmp_path):
     assert len(cands) == len(got) and 0 < len(got)
     assert sorted((c.level, c.root[1], c.root[0]) for c in cands) == sorted((k[0], k[2], k[3]) for k, _, _ in got)
     det.hd.close()
+
+
+@pytest.mark.parametrize("ext", ["yml", "xml"])
+def test_readers_on_documents_in_opencv_writer_layout(demo, ext):
+    """Hand-written documents in the layout OpenCV's FileStorage writer produces -- flow sequences wrapped over lines,
+    `!!opencv-matrix` / `type_id="opencv-matrix"` nodes, `<_>` items, an empty `defid` for the root -- committed under
+    tests/golden/ (not produced by this repository's writers; no file written by a real OpenCV ships with the reference,
+    so the reader stays "parity unpinned").  Python and C++ readers must agree with the values the files were typed from."""
+    path = os.path.join(ROOT, "tests", "golden", f"toy_model_opencv_layout.{ext}")
+    want_f = np.load(os.path.join(ROOT, "tests", "golden", "toy_model_opencv_layout_filters.npy"))
+    m = FS.deserialize(path)
+    assert (m.name, m.interval, m.sbin, m.norient, m.flen) == ("toy_opencv_layout", 4, 8, 18, 32) and m.thresh == -0.75
+    assert len(m.filtersw) == 3 and all(np.array_equal(a, b) for a, b in zip(m.filtersw, want_f))
+    assert np.array_equal(np.float32(m.biasw), np.float32([0.1, -0.2, 0.3, -0.4, 0.5]))
+    assert m.anchors == [(1, -2), (0, 3)] and m.parentid == [[-1, 0]]
+    assert m.filterid == [[[0], [1, 2]]] and m.biasid == [[[0], [1, 3]]] and m.defid == [[[], [0, 1]]]
+    assert np.array_equal(np.float32(m.defw), np.float32([[0.01, 0, 0.02, 0.001], [0.03, -0.001, 0.01, 0]]))
+    r = subprocess.run([demo, path, "--dump-model"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [ln.rstrip() for ln in r.stdout.strip().splitlines()]
+    want = _dump_digest(m)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a.split() == b.split(), (a[:100], b[:100])
