@@ -232,7 +232,7 @@ def main():
         if roof_all:
             roofline = roof_all[0]                           # the dominant kernel of this run
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (bench contract)
             # the GPU box's CPU share for one GPU is 16 cores; use at most that many OpenMP threads
             ncpu = min(len(os.sched_getaffinity(0)), 16)
             from oracle import oracle   # CPU restatement: the reported baseline, never the measured path
@@ -334,7 +334,7 @@ def main():
             "unit": "detections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: synthetic person model (26 parts x 6 mixtures = 156 filters "
+            "config": {"workload": f"BASELINE configs[{3 if (rows, cols) == (1080, 1920) else 2}]: synthetic person model (26 parts x 6 mixtures = 156 filters "
                                    f"5x5x32), batch of {B} {cols}x{rows} frames per GPU, full HOG+conv+DT/DP+argmin on GPU",
                        "frames_per_gpu_per_step": B, "conv_mode": args.conv_mode, "candidates_last_step": int(ncand),
                        "parallelism": f"frames sharded over {world} GPU(s), RCCL all_gather of candidates",
