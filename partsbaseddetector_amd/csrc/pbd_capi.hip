@@ -911,9 +911,9 @@ int build_model(pbd_handle *h, const pbd_model *m)
 // [f0, f0+nb) on stream `st` (no allocation, no synchronisation inside).
 int alloc_features(pbd_handle *h, Plan &P, int nframes, int cn)
 {
-    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * cn * depth_size(h->cur_depth) + 4));   // +4: 8-bit pixels are read as one 32-bit load
+    HIPCHK(h, h->pyr.ensure((size_t)nframes * P.pix_per_frame * cn * depth_size(h->cur_depth) + 32));   // slack: 8-bit pixels are read with 4- and 16-byte loads
     HIPCHK(h, h->gmag.ensure((size_t)nframes * P.pix_per_frame * h->rs));
-    HIPCHK(h, h->gori.ensure((size_t)nframes * P.pix_per_frame));
+    HIPCHK(h, h->gori.ensure((size_t)nframes * P.pix_per_frame + 16));
     HIPCHK(h, h->hist.ensure((size_t)nframes * P.blk_per_frame * 18 * h->rs));
     HIPCHK(h, h->norm.ensure((size_t)nframes * P.blk_per_frame * h->rs));
     HIPCHK(h, h->feat.ensure(std::max<size_t>((size_t)nframes * P.cell_per_frame * 32 * h->rs, 16)));
