@@ -119,15 +119,18 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 
     // The 8 N-tiles are done in two halves of 4 (64 accumulator registers instead of 128): with ~110 registers per
     // lane four waves fit a SIMD, so two or three 5-wave workgroups share a CU and one's matrix work covers the
     // others' staging and stores.  The weights are streamed twice (from L2).
-    constexpr int NH = NT / 2;
+    // N-tile groups per M-tile = work items per M-tile.  Measured (bf16, ms per step): 1 group (weights streamed once,
+    // 5 items over 4 waves) 8.1, 2 groups 7.8, 4 groups (weights streamed four times) 8.6
+    constexpr int NPART = 2;
+    constexpr int NH = NT / NPART;
     // work item = (M-tile, half): 10 of them, handed out to the workgroup's FOUR waves through an LDS counter (five
     // waves per workgroup would leave one SIMD with two: the second resident workgroup then rarely finds room)
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(next_item, 1);
         item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= MT * 2) break;
-        const int m = item >> 1, half = item & 1;
+        if (item >= MT * NPART) break;
+        const int m = item / NPART, half = item % NPART;
         if (pass * kMfmaFB + m * 32 >= p.F) continue;              // no filters in this M-tile
         // fragment stream of this M-tile: step s = tap * 2 + k-step; [s][m][v][lane]
         const u32x4 *wsrc = wfrag + ((size_t)pass * (K * K * 2) * MT + m) * NV * 64 + lane;
