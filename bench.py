@@ -177,6 +177,8 @@ def main():
         # ---- algorithmic work per STEP (one batch of B frames on this rank), SURVEY.md section 8(d) / DESIGN.md section 4
         def nmix(gp):
             return int(flat.mix_offset[gp + 1] - flat.mix_offset[gp])
+        # position planes are uint8 when no feature-map side exceeds 256 cells (the library picks this per plan), else int16
+        pb = 1 if max(int(plan["feat_rows"].max()), int(plan["feat_cols"].max())) <= 256 else 2
         jobs, comb, parents = 0, 0, set()
         for c in range(flat.ncomponents):
             p0 = int(flat.part_offset[c])
@@ -184,13 +186,13 @@ def main():
                 gpar = p0 + int(flat.parentid[gp])
                 K, L = nmix(gp), nmix(gpar)
                 jobs += K                                   # (part, mixture) distance transforms per level
-                comb += K * (4 + 2) + L * (2 + 5)           # per child: dt + Ix in, Iy gather, Ix/Iy/Ik out
+                comb += K * (4 + pb) + L * (pb + 2 * pb + 1)  # per child: dt + Ix in, Iy gather, Ix/Iy/Ik out
                 parents.add(gpar)
         comb += sum(8 * nmix(g) for g in parents)           # per parent: response in, accumulated score out
         work = {
             "k_conv": {"bytes": (128 * cells + 4 * F * ktaps + 4 * F * cells) * B, "flop": 2.0 * ktaps * F * cells * B},
-            "k_dt_rows": {"bytes": 10 * cells * jobs * B},      # read score 4, write tmp 4 + Ix 2
-            "k_dt_cols": {"bytes": 14 * cells * jobs * B},      # read tmp 4 + Ix 2, write dt 4 + Iy 2 + Ix 2
+            "k_dt_rows": {"bytes": (8 + pb) * cells * jobs * B},      # read score 4, write tmp 4 + Ix
+            "k_dt_cols": {"bytes": (8 + 3 * pb) * cells * jobs * B},  # read tmp 4 + Ix, write dt 4 + Iy + Ix
             "k_dp_combine": {"bytes": comb * cells * B},        # per child: dt/Ix in, Ix/Iy/Ik out; per parent: score in/out
             "k_hog_hist": {"bytes": (3 * int(np.sum(plan["img_rows"].astype(np.int64) * plan["img_cols"])) + 76 * cells) * B},
         }

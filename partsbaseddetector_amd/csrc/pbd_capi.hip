@@ -105,6 +105,7 @@ struct Plan {
     long long pix_per_frame = 0, blk_per_frame = 0, cell_per_frame = 0, npix_resized = 0, quad_per_frame = 0;
     int interval = 0;
     int nrows_flat = 0, ncols_flat = 0;
+    bool ptr8 = false;              // no feature map side exceeds 256: positions fit uint8 (back-pointer planes at half the bytes)
     int ntiles = 0;
     // device tables
     DevTable<LevelDesc> d_lv;
@@ -349,6 +350,11 @@ hipError_t finish_plan_tables(Plan &P)
                 for (int x0 = 0; x0 < d.cols; x0 += kConvTW) tiles.push_back({l, y0, x0});
             cover_level(l, d.rows, d.cols, shaped);
         }
+    }
+    {
+        int longest = 0;
+        for (const LevelDesc &d : P.lv) longest = std::max(longest, std::max(d.rows, d.cols));
+        P.ptr8 = longest <= 256;
     }
     rowoff[P.nlevels] = (int)row2level.size();
     coloff[P.nlevels] = (int)col2level.size();
@@ -1003,8 +1009,9 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     const size_t cpf = (size_t)P.cell_per_frame;
     const int NSa = std::max(h->NS, 1);
     HIPCHK(h, h->acc.ensure(std::max<size_t>((size_t)nframes * cpf * std::max(h->NM, 1) * h->rs, 16)));
-    HIPCHK(h, h->Ix.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(int16_t), 16)));
-    HIPCHK(h, h->Iy.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * sizeof(int16_t), 16)));
+    const size_t pes = P.ptr8 ? 1 : 2;        // bytes per position
+    HIPCHK(h, h->Ix.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * pes, 16)));
+    HIPCHK(h, h->Iy.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * pes, 16)));
     HIPCHK(h, h->Ik.ensure(std::max<size_t>((size_t)nframes * cpf * NSa, 16)));
     HIPCHK(h, h->rootv.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * h->rs, 16)));
     HIPCHK(h, h->rooti.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(int), 16)));
@@ -1012,9 +1019,9 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
     HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
-    HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
-    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
-    HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * sizeof(int16_t), 16)));
+    HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * pes, 16) + 16));      // + slack: 16-byte chunk reads
+    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16)));
+    HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16)));
     HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkPairF64 : kStkPairF32), 16)));
     return PBD_OK;
 }
@@ -1026,9 +1033,9 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC; dp.NM = h->NM;
     dp.cell_per_frame = P.cell_per_frame; dp.quad_per_frame = P.quad_per_frame; dp.max_mix = h->max_mix;
     dp.resp = h->resp.p; dp.resp_half = h->resp_half ? 1 : 0; dp.acc = h->acc.p;
-    dp.Ix = h->Ix.as<int16_t>(); dp.Iy = h->Iy.as<int16_t>(); dp.Ik = h->Ik.as<uint8_t>();
+    dp.Ix = h->Ix.p; dp.Iy = h->Iy.p; dp.Ik = h->Ik.as<uint8_t>(); dp.ptr8 = P.ptr8 ? 1 : 0;
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;
-    dp.IxT = h->IxT.as<int16_t>(); dp.IxRaw = h->IxRaw.as<int16_t>(); dp.IyRaw = h->IyRaw.as<int16_t>();
+    dp.IxT = h->IxT.p; dp.IxRaw = h->IxRaw.p; dp.IyRaw = h->IyRaw.p;
     dp.stk = h->stk.p; dp.stk_per_jf = P.stk_per_jf;
     dp.stk_row_off = P.d_stk_row_off.d; dp.stk_col_off = P.d_stk_col_off.d;
     dp.biasw = h->d_biasw.d;
@@ -1089,7 +1096,7 @@ ArgminParams argmin_params(pbd_handle *h, Plan &P, int nframes, const float *d_s
     ap.lv = P.d_lv.d; ap.nlevels = P.nlevels; ap.NS = h->NS; ap.NC = h->NC; ap.nframes = nframes;
     ap.cell_per_frame = P.cell_per_frame;
     ap.rootv = h->rootv.p; ap.rooti = h->rooti.as<int>();
-    ap.Ix = h->Ix.as<int16_t>(); ap.Iy = h->Iy.as<int16_t>(); ap.Ik = h->Ik.as<uint8_t>();
+    ap.Ix = h->Ix.p; ap.Iy = h->Iy.p; ap.Ik = h->Ik.as<uint8_t>(); ap.ptr8 = P.ptr8 ? 1 : 0;
     ap.thresh = h->thresh; ap.scales = d_scales;
     ap.walk = h->d_walk.d; ap.walk_off = h->d_walk_off.d;
     ap.max_parts = h->max_parts; ap.stride = 8 + 4 * h->max_parts; ap.capacity = std::max(h->cfg.max_candidates, 1);
@@ -1539,14 +1546,21 @@ int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, con
             const size_t n = hw * h->NS, off = (size_t)P->lv[l].cell_off * h->NS;
             if (n) {
                 t16.resize(n); t8.resize(n);
-                if (Ix && Ix[l]) {
-                    HIPCHK(h, hipMemcpy(t16.data(), h->Ix.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost));
-                    for (size_t i = 0; i < n; ++i) Ix[l][i] = t16[i];
-                }
-                if (Iy && Iy[l]) {
-                    HIPCHK(h, hipMemcpy(t16.data(), h->Iy.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost));
-                    for (size_t i = 0; i < n; ++i) Iy[l][i] = t16[i];
-                }
+                // positions are uint8 on the device when no level side exceeds 256 (Plan::ptr8), int16 otherwise
+                auto fetch_pos = [&](const DevBuf &src, int *dst) -> hipError_t {
+                    if (P->ptr8) {
+                        hipError_t e = hipMemcpy(t8.data(), src.as<uint8_t>() + off, n, hipMemcpyDeviceToHost);
+                        if (e != hipSuccess) return e;
+                        for (size_t i = 0; i < n; ++i) dst[i] = t8[i];
+                        return hipSuccess;
+                    }
+                    hipError_t e = hipMemcpy(t16.data(), src.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost);
+                    if (e != hipSuccess) return e;
+                    for (size_t i = 0; i < n; ++i) dst[i] = t16[i];
+                    return hipSuccess;
+                };
+                if (Ix && Ix[l]) HIPCHK(h, fetch_pos(h->Ix, Ix[l]));
+                if (Iy && Iy[l]) HIPCHK(h, fetch_pos(h->Iy, Iy[l]));
                 if (Ik && Ik[l]) {
                     HIPCHK(h, hipMemcpy(t8.data(), h->Ik.as<uint8_t>() + off, n, hipMemcpyDeviceToHost));
                     for (size_t i = 0; i < n; ++i) Ik[l][i] = t8[i];

@@ -162,15 +162,16 @@ struct DpParams {
     const void *resp;             // R, or fp16 when resp_half (PBD_CONV_MFMA_F16: BASELINE configs[4] "fp16 responses")
     int resp_half;
     void *acc;                    // R [frames][cell_per_frame*NM] accumulated scores of non-leaf parts
-    int16_t *Ix, *Iy;             // [frames][cell_per_frame*NS]
+    void *Ix, *Iy;                // [frames][cell_per_frame*NS] back-pointers: uint8 when ptr8 (no map side exceeds 256), else int16
     uint8_t *Ik;
+    int ptr8;
     // group scratch, indexed by chunk-local frame
     int JG;                       // jobs in this group
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
     long long quad_per_frame;
     int max_mix;                  // largest number of mixtures of any part of the model (<= kMaxMix)
-    int16_t *IxT;                 // rows-pass pointers, transposed [x][y]
-    int16_t *IxRaw, *IyRaw;       // row-major pointers written by the columns pass
+    void *IxT;                    // rows-pass pointers, transposed [x][y] (uint8 / int16 as Ix)
+    void *IxRaw, *IyRaw;          // row-major pointers written by the columns pass
     void *stk;                    // [chunk][JG][stk_per_jf] records of two entries, wave-private, lane-interleaved
     long long stk_per_jf;         // records per (job, frame)
     const long long *stk_row_off; // per rows-pass wave (64 flat rows): first entry
@@ -192,7 +193,8 @@ struct ArgminParams {
     int nlevels, NS, NC, nframes;
     long long cell_per_frame;
     const void *rootv; const int *rooti;   // rootv: R
-    const int16_t *Ix, *Iy; const uint8_t *Ik;
+    const void *Ix, *Iy; const uint8_t *Ik;
+    int ptr8;
     float thresh;
     const float *scales;          // [nlevels]
     const PartWalk *walk;         // all components concatenated

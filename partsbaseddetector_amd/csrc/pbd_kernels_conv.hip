@@ -158,7 +158,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) {
                     const v2f f = v2f{Ft[pp + i][j], Ft[pp + i][j]};
-                    // the first tap of a channel starts the sum: s = 0 + w*f (src/filter.cpp:3916), no separate zeroing
+                    // the first tap of a channel starts the sum.  The reference computes 0 + w*f (src/filter.cpp:3916); the
+                    // exact mode takes w*f itself: the two differ only when the product is -0 (0 + -0 = +0), a -0 can only
+                    // survive as a channel sum of -0, and the response it is added to starts at +0 and x + (+-0) == x
                     const bool first = (i == 0 && j == 0);
                     const v2f zero2 = v2f{0.0f, 0.0f};
                     if (FMA) {
@@ -170,7 +172,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #pragma unroll
                         for (int q = 0; q < Q / 2; ++q) tq[q] = w[q] * f;
 #pragma unroll
-                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = (first ? zero2 : s[pp][q]) + tq[q];
+                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = first ? tq[q] : s[pp][q] + tq[q];
                     }
                 }
             }

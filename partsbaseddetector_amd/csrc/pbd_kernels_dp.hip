@@ -18,6 +18,22 @@
 
 namespace pbd {
 
+// Instrumented build (-DPBD_DT_STATS, tools/dt_stats.sh): counts how often the wave executes each part of the transform
+// and for how many lanes -- the difference is what the lock step of 64 independent rows costs.  Not in the product build.
+#ifdef PBD_DT_STATS
+__device__ unsigned long long g_dt_stats[16];
+#define DT_STAT(i)                                                                                      \
+    do {                                                                                                \
+        const unsigned long long m_ = __ballot(1);                                                      \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                           \
+            atomicAdd(&g_dt_stats[2 * (i)], 1ull);                                                      \
+            atomicAdd(&g_dt_stats[2 * (i) + 1], (unsigned long long)__popcll(m_));                      \
+        }                                                                                               \
+    } while (0)
+#else
+#define DT_STAT(i)
+#endif
+
 template <typename R>
 __device__ __forceinline__ R quad_isect(double a, double b, int x0, int x1, R y0f, R y1f)
 {   // Quadratic::operator()(x0, x1, y0, y1), include/DistanceTransform.hpp:98-100, rounded to T
@@ -43,10 +59,12 @@ template <> struct RealLimits<double> { static __device__ __forceinline__ double
 //   * when a lane's ring is full its two oldest entries (2p, 2p+1) are spilled TOGETHER, as one 16-byte record
 //     {s[2p], s[2p+1], z[2p], v[2p] | v[2p+1] << 16}, to the wave-private, lane-interleaved global stack
 //     ([p][lane]); z[2p+1] is the intersection of the two, recomputed on reload with the same expression on the
-//     same operands (bit-identical).  With small deformation weights almost every parabola stays on the
-//     envelope, so nearly every entry makes this round trip, and since the lanes of a wave spill at different
-//     depths every lane's access is its own memory request: the passes are bound by the NUMBER of requests
-//     (a 6-byte s/v split over two stores was slower, doubling the fp64 divisions costs 3 %), which pairing halves;
+//     same operands (bit-identical).  A lane spills about once per ten elements, but with 64 independent lanes
+//     the WAVE runs the spill and reload paths about once per element (tools/dt_stats.sh: 0.78 and 1.17
+//     executions per element, 8 and 5 lanes active), each a memory round trip the whole wave waits for: what
+//     counts is the NUMBER of requests, which pairing halves (a 6-byte s/v split over two stores was slower; so
+//     was carrying z[2p+1] in a second 4-byte array to save the 24-instruction recomputation: rows pass 8.6 ->
+//     9.1 ms on the same box);
 //   * the read-out walks q downwards and POPS: since z[1..ktop] is strictly increasing,
 //     "k = 0; while (z[k+1] < os) k++" (DistanceTransform.hpp:172-178, q ascending) selects the same
 //     k(q) = max{k : z[k] < os(q)} as "k = ktop; while (!(z[k] < os)) k--" with q descending;
@@ -86,6 +104,7 @@ struct DtRing {
     {   // entry `idx` (the old top) moves under a new top
         const int slot = idx & (kDtT - 1);
         if (idx - lo >= kDtT) {   // ring full: spill its two oldest entries lo, lo + 1 as one record
+            DT_STAT(3);
             const int sl = lo & (kDtT - 1);
             g[(size_t)(lo >> 1) * 64] = StkPairT<R>{s(sl), s(sl + 1), z(sl), (unsigned)v(sl) | ((unsigned)v(sl + 1) << 16)};
             lo += 2;
@@ -100,6 +119,7 @@ struct DtRing {
         zk = z(slot); sk = s(slot); vk = v(slot);
         asm volatile("" : "+v"(zk), "+v"(sk), "+v"(vk));   // keep these as LDS reads (not a flat load of a selected pointer)
         if (idx < lo) {
+            DT_STAT(4);
             // the ring is empty (idx == lo - 1, odd): reload the pair (lo-2, lo-1); the lower entry goes back
             // into the ring, the upper one is the new top and gets its z recomputed
             const StkPairT<R> e = g[(size_t)((lo - 2) >> 1) * 64];
@@ -138,8 +158,10 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
             const int q = q0 + i;
             if (q >= 1 && q < N) {
                 const R sq = cur[i];
+                DT_STAT(0);
                 R s = quad_isect<R>(a, b, vk, q, sk, sq);
                 while (s <= zk && k > 0) {
+                    DT_STAT(1);
                     --k;
                     ring.pop(k, zk, sk, vk);
                     s = quad_isect<R>(a, b, vk, q, sk, sq);
@@ -169,7 +191,9 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
             const int q = q0 + i;
             if (q < N) {
                 const R osf = (R)(os0 + q);
+                DT_STAT(5);
                 while (!(zk < osf)) {   // z[0] = -inf ends the walk
+                    DT_STAT(2);
                     --k;
                     ring.pop(k, zk, sk, vk);
                 }
@@ -188,11 +212,13 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef short v8s_u __attribute__((ext_vector_type(8), aligned(2)));
 typedef _Float16 v8h_u __attribute__((ext_vector_type(8), aligned(2)));
+typedef unsigned char vchb_u __attribute__((ext_vector_type(PBD_DT_CH), aligned(1)));
 static_assert(kDtCH % 8 == 0, "the columns pass reads its int16 pointers 8 at a time");
 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
 // RH: the responses are fp16 (PBD_CONV_MFMA_F16); a template parameter so that the default kernels carry none of it
-template <typename R, bool RH>
+// PT: element type of the position planes (uint8_t when no map side exceeds 256, else int16_t)
+template <typename R, bool RH, typename PT>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
@@ -221,7 +247,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const int Hl = d.rows;
     const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y;
     R *tmpT = static_cast<R *>(p.tmp) + obase;
-    int16_t *ixT = p.IxT + obase;
+    PT *ixT = static_cast<PT *>(p.IxT) + obase;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     auto store = [&](int q0, const R *out, const int *ptr, const int *) {
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i)
-            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (int16_t)ptr[i]; }
+            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (PT)ptr[i]; }
     };
     auto noaux = [](int, int *) {};
     dt_stream<R, false>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
@@ -267,13 +293,18 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
     if (p.JG == 0 || p.nrows_flat == 0) return;
     const int nwv = (p.nrows_flat + 63) / 64;
     dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
-    if (f64) hipLaunchKernelGGL((k_dt_rows<double, false>), grid, dim3(64 * kDtWaves), 0, s, p);
-    else if (p.resp_half) hipLaunchKernelGGL((k_dt_rows<float, true>), grid, dim3(64 * kDtWaves), 0, s, p);
-    else hipLaunchKernelGGL((k_dt_rows<float, false>), grid, dim3(64 * kDtWaves), 0, s, p);
+#define PBD_ROWS(PT)                                                                                              \
+    do {                                                                                                          \
+        if (f64) hipLaunchKernelGGL((k_dt_rows<double, false, PT>), grid, dim3(64 * kDtWaves), 0, s, p);          \
+        else if (p.resp_half) hipLaunchKernelGGL((k_dt_rows<float, true, PT>), grid, dim3(64 * kDtWaves), 0, s, p); \
+        else hipLaunchKernelGGL((k_dt_rows<float, false, PT>), grid, dim3(64 * kDtWaves), 0, s, p);               \
+    } while (0)
+    if (p.ptr8) PBD_ROWS(uint8_t); else PBD_ROWS(int16_t);
+#undef PBD_ROWS
 }
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
-template <typename R>
+template <typename R, typename PT>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
 {
     const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // longest columns first, as in the rows pass
@@ -288,10 +319,10 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
     const DtJob job = p.jobs[j];
     const size_t jbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
     const R *tmpT = static_cast<const R *>(p.tmp) + jbase + (size_t)x * H;     // this lane's column, contiguous
-    const int16_t *ixT = p.IxT + jbase + (size_t)x * H;
+    const PT *ixT = static_cast<const PT *>(p.IxT) + jbase + (size_t)x * H;
     R *dt = static_cast<R *>(p.dt) + jbase + x;
-    int16_t *iyr = p.IyRaw + jbase + x;
-    int16_t *ixr = p.IxRaw + jbase + x;
+    PT *iyr = static_cast<PT *>(p.IyRaw) + jbase + x;
+    PT *ixr = static_cast<PT *>(p.IxRaw) + jbase + x;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
@@ -311,11 +342,17 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
     };
     auto aux = [&](int q0, int *buf) {      // the rows pass's pointers of this column
         if (q0 + kDtCH <= H) {
+            if constexpr (sizeof(PT) == 1) {
+                const vchb_u a0 = *reinterpret_cast<const vchb_u *>(ixT + q0);   // one load per chunk of uint8 positions
 #pragma unroll
-            for (int v = 0; v < kDtCH / 8; ++v) {
-                const v8s_u a0 = *reinterpret_cast<const v8s_u *>(ixT + q0 + 8 * v);
+                for (int e = 0; e < kDtCH; ++e) buf[e] = a0[e];
+            } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) buf[8 * v + e] = a0[e];
+                for (int v = 0; v < kDtCH / 8; ++v) {
+                    const v8s_u a0 = *reinterpret_cast<const v8s_u *>(ixT + q0 + 8 * v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) buf[8 * v + e] = a0[e];
+                }
             }
         } else {
 #pragma unroll
@@ -327,8 +364,8 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
         for (int i = 0; i < kDtCH; ++i)
             if (q0 + i < H) {
                 dt[(size_t)(q0 + i) * W] = out[i];
-                iyr[(size_t)(q0 + i) * W] = (int16_t)ptr[i];
-                ixr[(size_t)(q0 + i) * W] = (int16_t)ix[i];
+                iyr[(size_t)(q0 + i) * W] = (PT)ptr[i];
+                ixr[(size_t)(q0 + i) * W] = (PT)ix[i];
             }
     };
     dt_stream<R, true>(H, job.ay, job.by, job.osy, ring, load, store, aux);
@@ -339,8 +376,13 @@ void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
     if (p.JG == 0 || p.ncols_flat == 0) return;
     const int nwv = (p.ncols_flat + 63) / 64;
     dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
-    if (f64) hipLaunchKernelGGL(k_dt_cols<double>, grid, dim3(64 * kDtWaves), 0, s, p);
-    else hipLaunchKernelGGL(k_dt_cols<float>, grid, dim3(64 * kDtWaves), 0, s, p);
+    if (p.ptr8) {
+        if (f64) hipLaunchKernelGGL((k_dt_cols<double, uint8_t>), grid, dim3(64 * kDtWaves), 0, s, p);
+        else hipLaunchKernelGGL((k_dt_cols<float, uint8_t>), grid, dim3(64 * kDtWaves), 0, s, p);
+    } else {
+        if (f64) hipLaunchKernelGGL((k_dt_cols<double, int16_t>), grid, dim3(64 * kDtWaves), 0, s, p);
+        else hipLaunchKernelGGL((k_dt_cols<float, int16_t>), grid, dim3(64 * kDtWaves), 0, s, p);
+    }
 }
 
 // ---- combine: thread = 4 consecutive cells of one level, one PARENT part (block.y) ---------------------
@@ -384,7 +426,7 @@ __device__ __forceinline__ void store_cells(T *dst, int n, const T *src)
 }
 
 // MAXM: compile-time bound on the mixtures per part of the model (register arrays are sized by it)
-template <typename R, int kCpt, int MAXM, bool RH>
+template <typename R, int kCpt, int MAXM, bool RH, typename PT>
 __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
 {
     constexpr int SUB = 4 / kCpt;   // threads per group of 4 cells
@@ -448,20 +490,20 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
             for (int pm = 0; pm < MAXM; ++pm)
                 bw[mm][pm] = (mm < cd.nmix && pm < cj.npar) ? biasw[cd.bias_off[mm] + pm] : 0.0f;
         R dtv[MAXM][kCpt];
-        int16_t ixv[MAXM][kCpt];
+        PT ixv[MAXM][kCpt];
 #pragma unroll
         for (int mm = 0; mm < MAXM; ++mm) {
 #pragma unroll
             for (int e = 0; e < kCpt; ++e) { dtv[mm][e] = (R)0; ixv[mm][e] = 0; }
             if (mm < cd.nmix) {
                 load_cells<R, kCpt>(dtp + gbase + (size_t)mm * HW + local, n, dtv[mm]);
-                load_cells<int16_t, kCpt>(p.IxRaw + gbase + (size_t)mm * HW + local, n, ixv[mm]);
+                load_cells<PT, kCpt>(static_cast<const PT *>(p.IxRaw) + gbase + (size_t)mm * HW + local, n, ixv[mm]);
             }
         }
 #pragma unroll
         for (int pm = 0; pm < MAXM; ++pm) {
             if (pm < cj.npar) {
-                int16_t oix[kCpt], oiy[kCpt];
+                PT oix[kCpt], oiy[kCpt];
                 uint8_t oik[kCpt];
 #pragma unroll
                 for (int e = 0; e < kCpt; ++e) {
@@ -480,13 +522,13 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
                         }
                     }
                     int iy = 0;
-                    if (e < n) iy = p.IyRaw[gbase + (size_t)bi * HW + rowbase[e] + ix];
-                    oix[e] = (int16_t)ix; oiy[e] = (int16_t)iy; oik[e] = (uint8_t)bi;
+                    if (e < n) iy = static_cast<const PT *>(p.IyRaw)[gbase + (size_t)bi * HW + rowbase[e] + ix];
+                    oix[e] = (PT)ix; oiy[e] = (PT)iy; oik[e] = (uint8_t)bi;
                     accv[pm][e] = accv[pm][e] + best;
                 }
                 const size_t o = pbase + (size_t)(cd.slot + pm) * HW;
-                store_cells<int16_t, kCpt>(p.Ix + o, n, oix);
-                store_cells<int16_t, kCpt>(p.Iy + o, n, oiy);
+                store_cells<PT, kCpt>(static_cast<PT *>(p.Ix) + o, n, oix);
+                store_cells<PT, kCpt>(static_cast<PT *>(p.Iy) + o, n, oiy);
                 store_cells<uint8_t, kCpt>(p.Ik + o, n, oik);
             }
         }
@@ -503,9 +545,15 @@ void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hip
     const dim3 g2((unsigned)((p.quad_per_frame * 2 + 255) / 256), ncjobs, nframes), g4((unsigned)((p.quad_per_frame + 255) / 256), ncjobs, nframes);
 #define PBD_COMBINE(M)                                                                      \
     do {                                                                                    \
-        if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2, M, false>), g2, dim3(256), 0, s, p);   \
-        else if (p.resp_half) hipLaunchKernelGGL((k_dp_combine<float, 4, M, true>), g4, dim3(256), 0, s, p); \
-        else hipLaunchKernelGGL((k_dp_combine<float, 4, M, false>), g4, dim3(256), 0, s, p);        \
+        if (p.ptr8) {                                                                                                      \
+            if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2, M, false, uint8_t>), g2, dim3(256), 0, s, p);            \
+            else if (p.resp_half) hipLaunchKernelGGL((k_dp_combine<float, 4, M, true, uint8_t>), g4, dim3(256), 0, s, p); \
+            else hipLaunchKernelGGL((k_dp_combine<float, 4, M, false, uint8_t>), g4, dim3(256), 0, s, p);                 \
+        } else {                                                                                                           \
+            if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2, M, false, int16_t>), g2, dim3(256), 0, s, p);            \
+            else if (p.resp_half) hipLaunchKernelGGL((k_dp_combine<float, 4, M, true, int16_t>), g4, dim3(256), 0, s, p); \
+            else hipLaunchKernelGGL((k_dp_combine<float, 4, M, false, int16_t>), g4, dim3(256), 0, s, p);                 \
+        }                                                                                                                  \
     } while (0)
     if (p.max_mix <= 2) PBD_COMBINE(2);
     else if (p.max_mix <= 4) PBD_COMBINE(4);
@@ -518,7 +566,7 @@ void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hip
 // For every parent mixture pm, in order: weighted[mm] = score_dt[mm] + bias(mm)[pm]; reduceMax; pointer pick with the
 // Iy composition; then `parent.score[pm] += max` IN PLACE on the accumulator keyed by the parent mixture's filter id,
 // which starts as a copy of the raw response the first time it is touched (src/DynamicProgram.cpp:134-156).
-template <typename R>
+template <typename R, typename PT>
 __global__ __launch_bounds__(256) void k_dp_combine_seq(DpParams p)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,7 +589,7 @@ __global__ __launch_bounds__(256) void k_dp_combine_seq(DpParams p)
     int ixv[kMaxMix];
     for (int mm = 0; mm < sj.nmix; ++mm) {
         dtv[mm] = dtp[(size_t)mm * HW];
-        ixv[mm] = p.IxRaw[gbase + (size_t)mm * HW + local];
+        ixv[mm] = static_cast<const PT *>(p.IxRaw)[gbase + (size_t)mm * HW + local];
     }
     for (int pm = 0; pm < sj.npar; ++pm) {
         R best;
@@ -556,9 +604,9 @@ __global__ __launch_bounds__(256) void k_dp_combine_seq(DpParams p)
             }
         }
         const int ix = ixv[bi];
-        const int iy = p.IyRaw[gbase + (size_t)bi * HW + rowbase + ix];
+        const int iy = static_cast<const PT *>(p.IyRaw)[gbase + (size_t)bi * HW + rowbase + ix];
         const size_t o = pbase + (size_t)(sj.slot + pm) * HW;
-        p.Ix[o] = (int16_t)ix; p.Iy[o] = (int16_t)iy; p.Ik[o] = (uint8_t)bi;
+        static_cast<PT *>(p.Ix)[o] = (PT)ix; static_cast<PT *>(p.Iy)[o] = (PT)iy; p.Ik[o] = (uint8_t)bi;
         R *t = accp + (size_t)sj.target[pm] * HW;
         const R base = !sj.init[pm] ? *t
                        : (sizeof(R) == 4 && p.resp_half)
@@ -572,8 +620,13 @@ void launch_dp_combine_seq(const DpParams &p, int nsjobs, int nframes, bool f64,
 {
     if (nsjobs == 0 || p.cell_per_frame == 0) return;
     dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), nsjobs, nframes);
-    if (f64) hipLaunchKernelGGL(k_dp_combine_seq<double>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_dp_combine_seq<float>, grid, dim3(256), 0, s, p);
+    if (p.ptr8) {
+        if (f64) hipLaunchKernelGGL((k_dp_combine_seq<double, uint8_t>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_dp_combine_seq<float, uint8_t>), grid, dim3(256), 0, s, p);
+    } else {
+        if (f64) hipLaunchKernelGGL((k_dp_combine_seq<double, int16_t>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_dp_combine_seq<float, int16_t>), grid, dim3(256), 0, s, p);
+    }
 }
 
 // ---- root: rootv = max over root mixtures of (accumulated score + bias) ----------------------------
@@ -663,7 +716,7 @@ template <> __device__ __forceinline__ int round_mul<double>(int a, double s) { 
 // walk: one thread per candidate follows Ix/Iy/Ik from the root (src/DynamicProgram.cpp:218-244)
 // ncand < 0: the number of candidates is read from the device counter (pipelined entry points: the host does not
 // know it yet); the grid then strides over min(count, capacity) records
-template <typename R>
+template <typename R, typename PT>
 __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
 {
     if (ncand < 0) ncand = min(*p.count, p.capacity);
@@ -690,7 +743,7 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
             const PartWalk w = walk[pidx];
             const int px = xv[w.parent], py = yv[w.parent], pm = mv[w.parent];
             const size_t o = pbase + (size_t)(w.slot + pm) * HW + (size_t)py * W + px;
-            x = p.Ix[o]; y = p.Iy[o]; m = p.Ik[o];
+            x = static_cast<const PT *>(p.Ix)[o]; y = static_cast<const PT *>(p.Iy)[o]; m = p.Ik[o];
         }
         xv[pidx] = x; yv[pidx] = y; mv[pidx] = m;
         const int ks = walk[pidx].ksize[m];
@@ -711,8 +764,25 @@ void launch_argmin_walk(const ArgminParams &p, int ncand, bool f64, hipStream_t 
 {
     if (ncand == 0) return;
     const int blocks = ncand < 0 ? std::min((p.capacity + 63) / 64, 4096) : (ncand + 63) / 64;
-    if (f64) hipLaunchKernelGGL(k_argmin_walk<double>, dim3(blocks), dim3(64), 0, s, p, ncand);
-    else hipLaunchKernelGGL(k_argmin_walk<float>, dim3(blocks), dim3(64), 0, s, p, ncand);
+    if (p.ptr8) {
+        if (f64) hipLaunchKernelGGL((k_argmin_walk<double, uint8_t>), dim3(blocks), dim3(64), 0, s, p, ncand);
+        else hipLaunchKernelGGL((k_argmin_walk<float, uint8_t>), dim3(blocks), dim3(64), 0, s, p, ncand);
+    } else {
+        if (f64) hipLaunchKernelGGL((k_argmin_walk<double, int16_t>), dim3(blocks), dim3(64), 0, s, p, ncand);
+        else hipLaunchKernelGGL((k_argmin_walk<float, int16_t>), dim3(blocks), dim3(64), 0, s, p, ncand);
+    }
 }
 
 }  // namespace pbd
+
+#ifdef PBD_DT_STATS
+extern "C" int pbd_debug_dt_stats(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd::g_dt_stats), sizeof(pbd::g_dt_stats)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pbd::g_dt_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

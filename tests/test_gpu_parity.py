@@ -127,9 +127,9 @@ def test_conv_set_filters_replaces_model_filters(det_mod, oracle):
     hd.close()
 
 
-@pytest.mark.parametrize("which", ["tiny", "tiny_plain", "face", "person_small"])
+@pytest.mark.parametrize("which", ["tiny", "tiny_plain", "tiny_wide", "face", "person_small"])
 def test_dp_min(det_mod, oracle, which):
-    if which == "tiny":
+    if which in ("tiny", "tiny_wide"):
         model = M.synthetic_tiny_model(linear_def=True)
     elif which == "tiny_plain":
         model = M.synthetic_tiny_model(linear_def=False)
@@ -142,6 +142,8 @@ def test_dp_min(det_mod, oracle, which):
     dp = det_mod.DynamicProgram(hd)
     rng = np.random.default_rng(8)
     dims = [(21, 30), (9, 7), (1, 6), (5, 1)] if which != "person_small" else [(30, 41), (6, 5)]
+    if which == "tiny_wide":        # a side above 256 cells: the position planes are int16 instead of uint8
+        dims = [(5, 300), (270, 4), (3, 256), (2, 257)]
     scores = [rng.standard_normal((flat.nfilters, h, w)).astype(np.float32) for h, w in dims]
     Ix, Iy, Ik, rootv, rooti = dp.min(scores)
     for l, s in enumerate(scores):
@@ -162,6 +164,7 @@ def test_dp_min(det_mod, oracle, which):
 
 
 @pytest.mark.parametrize("which,shape,thresh", [("tiny", (96, 128), 0.6), ("tiny", (150, 101), 0.2),
+                                                 ("tiny", (44, 2200), 1.2),      # 548 cells wide: int16 position planes
                                                  ("face", (240, 320), None), ("person", (160, 120), None)])
 def test_detect_end_to_end(det_mod, oracle, which, shape, thresh):
     if which == "tiny":
