@@ -19,6 +19,7 @@
 #include "pbd_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace pbd {
 
@@ -102,19 +103,18 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 
     // filter groups are handed out dynamically: the 2 x NW waves of the resident workgroups do not spread
     // evenly over the 4 SIMDs, so waves on the less loaded SIMDs take more groups
-    for (;;) {
-        int g = 0;
-        if (lane == 0) g = atomicAdd(next_g, 1);
-        g = __builtin_amdgcn_readfirstlane(g);
-        if (g >= g1) break;
+    // QL = live filters of the group: 8, or 4 for a last group whose upper half is padding (156 filters = 19 groups of
+    // 8 + 4: the half group runs half the packed operations instead of multiplying zeros -- 2 % of the launch)
+    auto run_group = [&](auto ql_tag, const int g) {
+        constexpr int QL = decltype(ql_tag)::value, QH = QL / 2, NWV = QL / 4;
         const v4f *wsrc = reinterpret_cast<const v4f *>(wts + (size_t)g * 32 * WCH) + lane;
         v4f wreg = wl ? wsrc[0] : v4f{0.f, 0.f, 0.f, 0.f};
         if (wl) *reinterpret_cast<v4f *>(wbuf + lane * 4) = wreg;
-        v2f r[P][Q / 2];
+        v2f r[P][QH];
 #pragma unroll
         for (int pp = 0; pp < P; ++pp)
 #pragma unroll
-            for (int q = 0; q < Q / 2; ++q) r[pp][q] = v2f{0.0f, 0.0f};
+            for (int q = 0; q < QH; ++q) r[pp][q] = v2f{0.0f, 0.0f};
         // Software-pipelined sliding window.  A lane's 4 output rows see input rows 0..7 of the tile column; tap
         // row i uses rows i..i+3.  Every input row is read from LDS ONCE per channel, and the LDS reads of a stage
         // (one new row of this channel, one row of the next channel's first four, the 5 x 8 weights of the next
@@ -122,7 +122,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
         // stage does not touch -- a wave never waits for its own LDS reads.  Two channels per loop iteration keep
         // the buffer parity static (weights: 10 stages A B A B A | B A B A B; rows: even / odd channel).
         float Ft[P + K - 1][K];
-        v4f Wt[2][K][2];
+        v4f Wt[2][K][NWV];
         auto load_row = [&](int c, int r) {
             const float *sp = sp0 + c * PLANE + r * PW;
 #pragma unroll
@@ -132,29 +132,33 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
             const float *wcur = wbuf + (c & 1) * (WLANES * 4) + i * K * Q;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                Wt[buf][j][0] = *reinterpret_cast<const v4f *>(wcur + j * Q);
-                Wt[buf][j][1] = *reinterpret_cast<const v4f *>(wcur + j * Q + 4);
+#pragma unroll
+                for (int h = 0; h < NWV; ++h) Wt[buf][j][h] = *reinterpret_cast<const v4f *>(wcur + j * Q + 4 * h);
             }
         };
-        v2f s[P][Q / 2];
+        v2f s[P][QH];
         auto zero_s = [&]() {
 #pragma unroll
             for (int pp = 0; pp < P; ++pp)
 #pragma unroll
-                for (int q = 0; q < Q / 2; ++q) s[pp][q] = v2f{0.0f, 0.0f};
+                for (int q = 0; q < QH; ++q) s[pp][q] = v2f{0.0f, 0.0f};
         };
         auto add_s = [&]() {
 #pragma unroll
             for (int pp = 0; pp < P; ++pp)
 #pragma unroll
-                for (int q = 0; q < Q / 2; ++q) r[pp][q] = r[pp][q] + s[pp][q];
+                for (int q = 0; q < QH; ++q) r[pp][q] = r[pp][q] + s[pp][q];
         };
         auto comp = [&](int wbi, int i) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const v4f wa = Wt[wbi][j][0], wb = Wt[wbi][j][1];
-                const v2f w[Q / 2] = {__builtin_shufflevector(wa, wa, 0, 1), __builtin_shufflevector(wa, wa, 2, 3),
-                                      __builtin_shufflevector(wb, wb, 0, 1), __builtin_shufflevector(wb, wb, 2, 3)};
+                v2f w[QH];
+#pragma unroll
+                for (int h = 0; h < NWV; ++h) {
+                    const v4f wv = Wt[wbi][j][h];
+                    w[2 * h] = __builtin_shufflevector(wv, wv, 0, 1);
+                    w[2 * h + 1] = __builtin_shufflevector(wv, wv, 2, 3);
+                }
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) {
                     const v2f f = v2f{Ft[pp + i][j], Ft[pp + i][j]};
@@ -165,14 +169,14 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
                     const v2f zero2 = v2f{0.0f, 0.0f};
                     if (FMA) {
 #pragma unroll
-                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = __builtin_elementwise_fma(w[q], f, first ? zero2 : s[pp][q]);
+                        for (int q = 0; q < QH; ++q) s[pp][q] = __builtin_elementwise_fma(w[q], f, first ? zero2 : s[pp][q]);
                     } else {
                         // four products, then their four additions: an addition issues 16 cycles after its product
-                        v2f tq[Q / 2];
+                        v2f tq[QH];
 #pragma unroll
-                        for (int q = 0; q < Q / 2; ++q) tq[q] = w[q] * f;
+                        for (int q = 0; q < QH; ++q) tq[q] = w[q] * f;
 #pragma unroll
-                        for (int q = 0; q < Q / 2; ++q) s[pp][q] = first ? tq[q] : s[pp][q] + tq[q];
+                        for (int q = 0; q < QH; ++q) s[pp][q] = first ? tq[q] : s[pp][q] + tq[q];
                     }
                 }
             }
@@ -183,9 +187,15 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
         // loads of later stages, the 16 accumulators pass through an empty asm with a memory clobber at both ends
         // of every stage (the loads cannot cross it, the operations are tied to it through their operands).
 #define PBD_PIN()                                                                                                          \
-    asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), \
-                 "+v"(s[1][3]), "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[2][2]), "+v"(s[2][3]), "+v"(s[3][0]), "+v"(s[3][1]),     \
-                 "+v"(s[3][2]), "+v"(s[3][3])::"memory")
+    do {                                                                                                                   \
+        if constexpr (QL == 8)                                                                                             \
+            asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][QH - 2]), "+v"(s[0][QH - 1]), "+v"(s[1][0]), "+v"(s[1][1]),      \
+                         "+v"(s[1][QH - 2]), "+v"(s[1][QH - 1]), "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[2][QH - 2]), "+v"(s[2][QH - 1]), \
+                         "+v"(s[3][0]), "+v"(s[3][1]), "+v"(s[3][QH - 2]), "+v"(s[3][QH - 1])::"memory");                    \
+        else                                                                                                               \
+            asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[2][0]), "+v"(s[2][1]),    \
+                         "+v"(s[3][0]), "+v"(s[3][1])::"memory");                                                          \
+    } while (0)
 #define PBD_STAGE(LOADS, WB, I)                  \
     do {                                         \
         LOADS;                                   \
@@ -225,13 +235,13 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #undef PBD_PIN
         // a full group (all but possibly the last) stores without per-filter branches: one block of 8
         // independent stores per row
-        if (g * Q + Q <= p.nf && p.fmap == nullptr) {
+        if (g * Q + QL <= p.nf && p.fmap == nullptr) {
             float *rg = resp + (size_t)(g * Q) * HW;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
                 if (x < W && y + pp < H) {
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) rg[(size_t)q * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
+                    for (int q = 0; q < QL; ++q) rg[(size_t)q * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
                 }
             }
         } else if (x < W) {
@@ -239,13 +249,22 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
             for (int pp = 0; pp < P; ++pp) {
                 if (y + pp < H) {
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) {
+                    for (int q = 0; q < QL; ++q) {
                         const int f = g * Q + q;
                         if (f < p.nf) resp[(size_t)(p.fmap ? p.fmap[f] : f) * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
                     }
                 }
             }
         }
+    };
+    const int half_g = (p.nf % Q != 0 && p.nf % Q <= Q / 2) ? ngroups - 1 : -1;   // the group whose upper half is padding
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(next_g, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= g1) break;
+        if (g == half_g) run_group(std::integral_constant<int, Q / 2>{}, g);
+        else run_group(std::integral_constant<int, Q>{}, g);
     }
 }
 
