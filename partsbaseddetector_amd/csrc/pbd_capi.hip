@@ -113,15 +113,15 @@ struct Plan {
     DevTable<ResizeTabY> d_taby;
     DevTable<ResizeTabXf> d_tabxf;   // the same mapping with float coefficients (16U / 32F / 64F images)
     DevTable<ResizeTabYf> d_tabyf;
-    DevTable<ConvTile> d_tiles, d_shaped;
-    int nshaped[3] = {0, 0, 0};
+    DevTable<ConvTile> d_tiles, d_shaped, d_htiles;
+    int nshaped[3] = {0, 0, 0}, nhtiles = 0;
     DevTable<int> d_row2level, d_rowoff, d_col2level, d_coloff;
     DevTable<long long> d_stk_row_off, d_stk_col_off;
     long long stk_per_jf = 0;
     DevTable<float> d_scales;
     void release()
     {
-        d_lv.release(); d_tabx.release(); d_taby.release(); d_tabxf.release(); d_tabyf.release(); d_tiles.release(); d_shaped.release();
+        d_lv.release(); d_tabx.release(); d_taby.release(); d_tabxf.release(); d_tabyf.release(); d_tiles.release(); d_shaped.release(); d_htiles.release();
         d_row2level.release(); d_rowoff.release(); d_col2level.release(); d_coloff.release(); d_scales.release();
         d_stk_row_off.release(); d_stk_col_off.release();
     }
@@ -331,16 +331,18 @@ static void cover_level(int l, int rows, int cols, std::vector<ConvTile> *shaped
     }
 }
 
-hipError_t finish_plan_tables(Plan &P)
+hipError_t finish_plan_tables(Plan &P, int sbin)
 {
     // flat row / column lookup and conv tiles over the feature maps
     std::vector<int> row2level, rowoff(P.nlevels + 1, 0), col2level, coloff(P.nlevels + 1, 0);
-    std::vector<ConvTile> tiles, shaped[3];
+    std::vector<ConvTile> tiles, shaped[3], htiles;
     P.quad_per_frame = 0;
     for (int l = 0; l < P.nlevels; ++l) {
         P.lv[l].quad_off = P.quad_per_frame;
         P.quad_per_frame += ((long long)P.lv[l].rows * P.lv[l].cols + 3) / 4;
         const LevelDesc &d = P.lv[l];
+        for (int by0 = 0; by0 < d.blk_rows && d.blk_cols > 0; by0 += hog_tile_rows(sbin))
+            for (int bx0 = 0; bx0 < d.blk_cols; bx0 += kHogTBX) htiles.push_back({l, by0, bx0});
         rowoff[l] = (int)row2level.size();
         coloff[l] = (int)col2level.size();
         if (d.rows > 0 && d.cols > 0) {
@@ -361,6 +363,7 @@ hipError_t finish_plan_tables(Plan &P)
     P.nrows_flat = (int)row2level.size();
     P.ncols_flat = (int)col2level.size();
     P.ntiles = (int)tiles.size();
+    P.nhtiles = (int)htiles.size();
     // wave-private stack regions: a wave of 64 flat rows (columns) needs 64 x ceil(longest row in the wave / 2)
     // two-entry records; levels are ordered large to small, but take the maximum to be safe
     std::vector<long long> srow, scol;
@@ -386,6 +389,7 @@ hipError_t finish_plan_tables(Plan &P)
     if ((e = P.d_lv.upload(P.lv)) != hipSuccess) return e;
     if ((e = P.d_tiles.upload(tiles)) != hipSuccess) return e;
     if ((e = P.d_shaped.upload(all)) != hipSuccess) return e;
+    if ((e = P.d_htiles.upload(htiles)) != hipSuccess) return e;
     if ((e = P.d_row2level.upload(row2level)) != hipSuccess) return e;
     if ((e = P.d_rowoff.upload(rowoff)) != hipSuccess) return e;
     if ((e = P.d_col2level.upload(col2level)) != hipSuccess) return e;
@@ -497,7 +501,7 @@ int get_image_plan(pbd_handle *h, int rows, int cols, Plan **out)
     HIPCHK(h, P->d_taby.upload(taby));
     HIPCHK(h, P->d_tabxf.upload(tabxf));
     HIPCHK(h, P->d_tabyf.upload(tabyf));
-    HIPCHK(h, finish_plan_tables(*P));
+    HIPCHK(h, finish_plan_tables(*P, h->sbin));
     // HOG coordinate table grows with the largest frame seen
     const int need = std::max(rows, cols) + 4 * h->sbin + 8;
     if (need > h->coord_n) {
@@ -554,7 +558,7 @@ int get_dims_plan(pbd_handle *h, int nlevels, const int *rows, const int *cols, 
         cell += (long long)rows[l] * cols[l];
     }
     P->cell_per_frame = cell;
-    HIPCHK(h, finish_plan_tables(*P));
+    HIPCHK(h, finish_plan_tables(*P, h->sbin));
     *out = P.get();
     cache_plan(h, std::move(P));
     return PBD_OK;
@@ -950,6 +954,7 @@ void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int cn, int f
     hp.pyr = h->pyr.as<uint8_t>(); hp.depth = h->cur_depth; hp.coord = h->d_coord.p;
     hp.gmag = h->gmag.p; hp.gori = h->gori.as<uint8_t>();
     hp.hist = h->hist.p; hp.norm = h->norm.p; hp.feat = h->feat.p;
+    hp.htiles = P.d_htiles.d; hp.nhtiles = P.nhtiles;
     {
         ProfScope ps(h, PBD_K_HOG_HIST, st);
         launch_hog_hist(hp, nb, h->f64, st);

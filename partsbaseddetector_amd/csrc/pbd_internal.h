@@ -42,6 +42,9 @@ typedef HogCoordT<float> HogCoord;
 typedef HogCoordT<double> HogCoordD;
 
 struct ConvTile { int level; int y0, x0; };
+// tile of HOG blocks handled by one workgroup of the fused gradient + histogram kernel: kHogTBX x hog_tile_rows(sbin)
+constexpr int kHogTBX = 16;
+inline int hog_tile_rows(int sbin) { return sbin <= 4 ? 16 : 8; }
 
 // distance-transform job = (part, mixture) of one tree-depth group.  Its input is ONE plane: the raw
 // response of its filter for a leaf part, or the accumulated score (response + children's messages,
@@ -133,6 +136,8 @@ struct HogParams {
     void *hist;                   // R [frames][18][blk_per_frame]
     void *norm;                   // R [frames][blk_per_frame]
     void *feat;                   // R [frames][cell_per_frame*32]
+    const ConvTile *htiles;       // block tiles of the fused gradient + histogram kernel ({level, by0, bx0})
+    int nhtiles;
 };
 
 struct ConvParams {

@@ -5,6 +5,8 @@
 // -ffp-contract=off so no multiply-add is fused.
 #include "pbd_internal.h"
 
+#include <stdlib.h>
+
 namespace pbd {
 
 // level containing flat element `idx` for the offsets selected by OFF (0 img, 1 blk, 2 cell)
@@ -335,13 +337,39 @@ __device__ __forceinline__ void hog_grad_pixel(R dxb, R dyb, R dxg, R dyg, R dxr
     R v = dx * dx + dy * dy;
     if (vg > v) { v = vg; dx = dxg; dy = dyg; }
     if (vb > v) { v = vb; dx = dxb; dy = dyb; }
+    // The reference's scan, k ascending: "if (dot > best) {best = dot; o = k} else if (-dot > best) {best = -dot; o = k + 9}".
+    // best is never negative, so at most one of the two tests can pass and the pair is "|dot| > best" with the sign of dot
+    // choosing k or k + 9 (a NaN fails every test in both forms).  The tables are antisymmetric / symmetric about k = 4.5
+    // (uu[9-j] = -uu[j], vv[9-j] = vv[j]) and rounding is sign-symmetric, so uu[9-j]*dx + vv[9-j]*dy is, bit for bit,
+    // vv[j]*dy - uu[j]*dx: eight products and eight sums instead of eighteen and nine; uu[0]*dx + vv[0]*dy is 1*dx + 0*dy.
+    R dots[9];
+    dots[0] = uu[0] * dx + vv[0] * dy;
+#pragma unroll
+    for (int j = 1; j <= 4; ++j) {
+        const R pa = uu[j] * dx, pb = vv[j] * dy;
+        dots[j] = pa + pb;
+        dots[9 - j] = pb - pa;
+    }
     R best_dot = (R)0;
     int best_o = 0;
+    if constexpr (sizeof(R) == 4) {
+        // the winner is carried as k | sign bit of its dot product: one and-or per candidate, the k + 9 resolved at the end
+        unsigned code = 0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const R dot = uu[k] * dx + vv[k] * dy;
-        if (dot > best_dot) { best_dot = dot; best_o = k; }
-        else if (-dot > best_dot) { best_dot = -dot; best_o = k + 9; }
+        for (int k = 0; k < 9; ++k) {
+            const float ad = __builtin_fabsf(dots[k]);
+            const bool win = ad > best_dot;
+            code = win ? ((__float_as_uint(dots[k]) & 0x80000000u) | (unsigned)k) : code;
+            best_dot = win ? ad : best_dot;
+        }
+        best_o = (int)(code & 0xfu) + ((code >> 31) ? 9 : 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const R dot = dots[k];
+            const R ad = dot < (R)0 ? -dot : dot;
+            if (ad > best_dot) { best_dot = ad; best_o = dot < (R)0 ? k + 9 : k; }
+        }
     }
     mag = real_sqrt<R>(v);
     ori = best_o;
@@ -579,8 +607,147 @@ __global__ __launch_bounds__(256) void k_hog_hist(HogParams p)
     static_cast<R *>(p.norm)[(size_t)frame * p.blk_per_frame + idx] = e;
 }
 
+// Fused form of the two passes for the hot case (8-bit BGR frames, T = float, sbin 4 or 8): one workgroup = one tile of
+// TBX x TBY blocks.  The gradient magnitude / orientation of the pixels its blocks sample ((TB-1)*SB + 2*SB + 2 per side)
+// are computed straight from the level image into LDS, four pixels per lane as in k_hog_grad4, and the block threads
+// then walk their windows there: the 5 bytes per pixel of pass 1 never travel to HBM and back (they were 2/3 of the
+// two kernels' traffic, each pixel being re-read by four blocks), and the window reads, SB apart between lanes in
+// global memory, become LDS reads.  Arithmetic and addition order per bin are those of the two kernels above.
+template <int SB, int TBX, int TBY>
+__global__ __launch_bounds__(TBX * TBY) void k_hog_tile(HogParams p)
+{
+    constexpr int NT = TBX * TBY;
+    constexpr int LO = (SB + 1) / 2 + 1;                           // pixels sampled left of / above the tile's first block
+    constexpr int PWX = SB * (TBX - 1) + (3 * SB + 1) / 2 + 1 + LO, PWY = SB * (TBY - 1) + (3 * SB + 1) / 2 + 1 + LO;
+    constexpr int LW = (PWX + 3) & ~3, NQ = LW / 4;
+    __shared__ float s_mag[PWY * LW];
+    __shared__ uint8_t s_ori[PWY * LW];
+    __shared__ float bins[18 * NT];
+    const ConvTile tile = p.htiles[blockIdx.x];
+    const int frame = p.frame0 + blockIdx.y;
+    const LevelDesc d = p.lv[tile.level];
+    const int rows = d.img_rows, cols = d.img_cols;
+    const int t = threadIdx.x;
+    const int ox = SB * tile.x0 - LO, oy = SB * tile.y0 - LO;     // image position of LDS cell (0, 0); ConvTile::{y0, x0} = first block
+    const uint8_t *im = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off) * 3;
+    const size_t stride = (size_t)cols * 3;
+    const long long npix = (long long)rows * cols;
+#ifdef PBD_HOG_ABL_NOA
+    for (int q = t; q < PWY * LW; q += NT) { s_mag[q] = 1.0f; s_ori[q] = (uint8_t)(q % 18); }
+    if (false)
+#endif
+    for (int q = t; q < PWY * NQ; q += NT) {
+        const int py = q / NQ, px = (q - py * NQ) * 4;
+        const int y = oy + py, x = ox + px;
+        if (y < 1 || y > rows - 2) continue;                       // never sampled (positions are clamped to rows-2 / cols-2)
+        const uint8_t *s = im + 3 * x + (size_t)y * stride;
+        if (x >= 1 && x + 3 <= cols - 2 && (long long)y * cols + x + 3 < npix) {
+            const u32x4_u up = *reinterpret_cast<const u32x4_u *>(s - stride), dn = *reinterpret_cast<const u32x4_u *>(s + stride);
+            const u32x4_u mid = *reinterpret_cast<const u32x4_u *>(s - 3);
+            const uint32_t mid2 = *reinterpret_cast<const u32_unaligned *>(s + 13);
+            f32x4_u mg;
+            uint32_t og = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float m; int oo;
+                hog_grad_pixel<float>((float)(px_byte(mid, mid2, 3 * (i + 2) + 0) - px_byte(mid, mid2, 3 * i + 0)),
+                                      (float)(px_byte(dn, 0, 3 * i + 0) - px_byte(up, 0, 3 * i + 0)),
+                                      (float)(px_byte(mid, mid2, 3 * (i + 2) + 1) - px_byte(mid, mid2, 3 * i + 1)),
+                                      (float)(px_byte(dn, 0, 3 * i + 1) - px_byte(up, 0, 3 * i + 1)),
+                                      (float)(px_byte(mid, mid2, 3 * (i + 2) + 2) - px_byte(mid, mid2, 3 * i + 2)),
+                                      (float)(px_byte(dn, 0, 3 * i + 2) - px_byte(up, 0, 3 * i + 2)), m, oo);
+                mg[i] = m;
+                og |= (uint32_t)oo << (8 * i);
+            }
+            *reinterpret_cast<f32x4_u *>(s_mag + py * LW + px) = mg;
+            *reinterpret_cast<uint32_t *>(s_ori + py * LW + px) = og;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xi = x + i;
+                if (xi < 1 || xi > cols - 2) continue;
+                const uint8_t *si = s + 3 * i;
+                const uint32_t pd = load_px3(si + stride), pu = load_px3(si - stride), pr = load_px3(si + 3), pl = load_px3(si - 3);
+                float m; int oo;
+                hog_grad_pixel<float>((float)(px_ch(pr, 0) - px_ch(pl, 0)), (float)(px_ch(pd, 0) - px_ch(pu, 0)),
+                                      (float)(px_ch(pr, 1) - px_ch(pl, 1)), (float)(px_ch(pd, 1) - px_ch(pu, 1)),
+                                      (float)(px_ch(pr, 2) - px_ch(pl, 2)), (float)(px_ch(pd, 2) - px_ch(pu, 2)), m, oo);
+                s_mag[py * LW + px + i] = m;
+                s_ori[py * LW + px + i] = (uint8_t)oo;
+            }
+        }
+    }
+    __syncthreads();
+    const int by = tile.y0 + t / TBX, bx = tile.x0 + t % TBX;
+    if (by >= d.blk_rows || bx >= d.blk_cols) return;
+    const int vish = d.blk_rows * SB, visw = d.blk_cols * SB;
+    const HogCoordT<float> *coord = static_cast<const HogCoordT<float> *>(p.coord);
+    float *h = bins + t;
+#pragma unroll
+    for (int o = 0; o < 18; ++o) h[o * NT] = 0.0f;
+    int ylo = SB * by - (SB + 1) / 2 - 1, yhi = SB * by + (3 * SB + 1) / 2 + 1;
+    int xlo = SB * bx - (SB + 1) / 2 - 1, xhi = SB * bx + (3 * SB + 1) / 2 + 1;
+    if (ylo < 1) ylo = 1;
+    if (xlo < 1) xlo = 1;
+    if (yhi > vish - 1) yhi = vish - 1;
+    if (xhi > visw - 1) xhi = visw - 1;
+    constexpr int NX = 2 * SB + 2;                             // window width before clamping
+    const int x0 = SB * bx - (SB + 1) / 2 - 1;
+    float wxs[NX];
+    int xoff[NX];                                               // LDS column, -1: this x does not feed the block
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int x = x0 + i;
+        xoff[i] = -1; wxs[i] = 0.0f;
+        if (x >= xlo && x < xhi) {
+            const HogCoordT<float> cx = coord[x];
+            if (cx.ip == bx) { wxs[i] = cx.v1; xoff[i] = (x < cols - 2 ? x : cols - 2) - ox; }
+            else if (cx.ip + 1 == bx) { wxs[i] = cx.v0; xoff[i] = (x < cols - 2 ? x : cols - 2) - ox; }
+        }
+    }
+#ifdef PBD_HOG_ABL_NOB
+    if (s_mag[t] == 123.0f)
+#endif
+    for (int y = ylo; y < yhi; ++y) {
+        const HogCoordT<float> cy = coord[y];
+        float wy;
+        if (cy.ip == by) wy = cy.v1;
+        else if (cy.ip + 1 == by) wy = cy.v0;
+        else continue;
+        const int rowg = ((y < rows - 2 ? y : rows - 2) - oy) * LW;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (xoff[i] < 0) continue;
+            const int g = rowg + xoff[i];
+            const float contrib = (wy * wxs[i]) * s_mag[g];
+            float *bin = h + (int)s_ori[g] * NT;
+            *bin = *bin + contrib;
+        }
+    }
+    const long long idx = d.blk_off + (long long)by * d.blk_cols + bx;
+    float *hist = static_cast<float *>(p.hist) + (size_t)frame * 18 * p.blk_per_frame + idx;
+    float hv[18];
+#pragma unroll
+    for (int o = 0; o < 18; ++o) { hv[o] = h[o * NT]; hist[(size_t)o * p.blk_per_frame] = hv[o]; }
+    float e = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+        const float tt = hv[o] + hv[o + 9];
+        e += tt * tt;
+    }
+    static_cast<float *>(p.norm)[(size_t)frame * p.blk_per_frame + idx] = e;
+}
+
 void launch_hog_hist(const HogParams &p, int nframes, bool f64, hipStream_t s)
 {
+    static const bool two_pass = getenv("PBD_HOG_TWO_PASS") != nullptr;     // A/B switch: the unfused kernels
+    if (!f64 && p.depth == kDepth8U && p.cn == 3 && (p.sbin == 4 || p.sbin == 8) && !two_pass) {
+        if (p.nhtiles == 0) return;
+        dim3 grid((unsigned)p.nhtiles, nframes);
+        if (p.sbin == 4) hipLaunchKernelGGL((k_hog_tile<4, kHogTBX, 16>), grid, dim3(kHogTBX * 16), 0, s, p);
+        else hipLaunchKernelGGL((k_hog_tile<8, kHogTBX, 8>), grid, dim3(kHogTBX * 8), 0, s, p);
+        return;
+    }
     dim3 gridp((unsigned)((p.pix_per_frame + 255) / 256), nframes);
 #define PBD_GRAD(PT)                                                                            \
     do {                                                                                        \
