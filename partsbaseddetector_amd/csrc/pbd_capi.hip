@@ -134,6 +134,7 @@ struct Group {   // DT jobs of the parts of one tree depth + combine jobs of the
     std::vector<CombineJob> cjobs;
     std::vector<SeqCombineJob> sjobs;     // sequential schedule (shared filter ids): replaces childs / cjobs
     DevTable<DtJob> d_jobs;
+    int bz_x = 0, bz_y = 0;               // all jobs: linear coefficient exactly -0.0 and a != 0 (DpParams::bz_x / bz_y)
     DevTable<ChildDesc> d_childs;
     DevTable<CombineJob> d_cjobs;
     DevTable<SeqCombineJob> d_sjobs;
@@ -880,6 +881,13 @@ int build_model(pbd_handle *h, const pbd_model *m)
     }
     for (auto &g : h->groups) {
         HIPCHK(h, g.d_jobs.upload(g.jobs));
+        // the usual deformation (w1 = w3 = +0.0f, so b = -0.0): the passes then run without the b terms
+        auto neg_zero = [](double v) { return v == 0.0 && std::signbit(v); };
+        g.bz_x = g.bz_y = 1;
+        for (const DtJob &j : g.jobs) {
+            if (!(neg_zero(j.bx) && j.ax != 0.0)) g.bz_x = 0;
+            if (!(neg_zero(j.by) && j.ay != 0.0)) g.bz_y = 0;
+        }
         HIPCHK(h, g.d_childs.upload(g.childs));
         HIPCHK(h, g.d_cjobs.upload(g.cjobs));
         HIPCHK(h, g.d_sjobs.upload(g.sjobs));
@@ -1051,6 +1059,7 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     for (auto &g : h->groups) {
         dp.JG = (int)g.jobs.size();
         dp.jobs = g.d_jobs.d; dp.cjobs = g.d_cjobs.d; dp.childs = g.d_childs.d;
+        dp.bz_x = g.bz_x; dp.bz_y = g.bz_y;
         { ProfScope ps(h, PBD_K_DT_ROWS, st); launch_dt_rows(dp, nb, h->f64, st); }
         { ProfScope ps(h, PBD_K_DT_COLS, st); launch_dt_cols(dp, nb, h->f64, st); }
         dp.sjobs = g.d_sjobs.d;

@@ -165,6 +165,7 @@ struct DpParams {
     long long cell_per_frame;
     int frame0;                   // first frame of this chunk (absolute index into resp/msg/ptr buffers)
     const void *resp;             // R, or fp16 when resp_half (PBD_CONV_MFMA_F16: BASELINE configs[4] "fp16 responses")
+    int bz_x, bz_y;               // every job of the launch has a linear coefficient of exactly -0.0 (and a != 0) along x / y
     int resp_half;
     void *acc;                    // R [frames][cell_per_frame*NM] accumulated scores of non-leaf parts
     void *Ix, *Iy;                // [frames][cell_per_frame*NS] back-pointers: uint8 when ptr8 (no map side exceeds 256), else int16

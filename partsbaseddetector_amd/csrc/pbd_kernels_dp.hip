@@ -34,17 +34,27 @@ __device__ unsigned long long g_dt_stats[16];
 #define DT_STAT(i)
 #endif
 
-template <typename R>
+// BZ: the linear coefficient b is exactly -0.0 (deformation weight +0.0f, the usual model) and a != 0.  Then
+// b * d is -0.0 for the d > 0 of an intersection and (y1 - y0) - (-0.0) == y1 - y0 for every value, -0.0 included;
+// in the value expression b * x is +-0 and a * x*x + (+-0) == a * x*x unless that is itself a zero of the other
+// sign, which happens only for x == 0, where b * x = -0.0 * 0 = -0.0 and t + (-0.0) == t for every t.
+template <typename R, bool BZ>
 __device__ __forceinline__ R quad_isect(double a, double b, int x0, int x1, R y0f, R y1f)
 {   // Quadratic::operator()(x0, x1, y0, y1), include/DistanceTransform.hpp:98-100, rounded to T
     const double y0 = (double)y0f, y1 = (double)y1f;
-    const double num = ((y1 - y0) - b * (double)(x1 - x0)) + a * (double)(x1 * x1 - x0 * x0);
-    return (R)(num / ((2 * a) * (double)(x1 - x0)));
+    // x1*x1 - x0*x0 as (x1 - x0) * (x1 + x0): the same integer (0 <= x0 < x1 < 2^16), one 24-bit multiply instead of two
+    // full-width ones (quarter rate on this VALU)
+    const int dx = x1 - x0;
+    const double dd = (double)dx;
+    const double sq = (double)(int)__umul24((unsigned)dx, (unsigned)(x1 + x0));
+    const double num = BZ ? (y1 - y0) + a * sq : ((y1 - y0) - b * dd) + a * sq;
+    return (R)(num / ((2 * a) * dd));
 }
-template <typename R>
+template <typename R, bool BZ>
 __device__ __forceinline__ R quad_val(double a, double b, int x, R y)
 {   // Quadratic::operator()(x, y), :103-105
-    return (R)((a * (double)(x * x) + b * (double)x) + (double)y);
+    if (BZ) return (R)(a * (double)__mul24(x, x) + (double)y);
+    return (R)((a * (double)__mul24(x, x) + b * (double)x) + (double)y);     // |x| < 2^16
 }
 template <typename R> struct RealLimits;
 template <> struct RealLimits<float> { static __device__ __forceinline__ float inf() { return INFINITY; } };
@@ -111,6 +121,7 @@ struct DtRing {
         }
         z(slot) = zk; s(slot) = sk; v(slot) = vk;
     }
+    template <bool BZ>
     __device__ __forceinline__ void pop(int idx, R &zk, R &sk, int &vk)
     {   // entry `idx` becomes the top
         // the ring slot is read unconditionally (always a valid LDS address) so that the common case is
@@ -127,7 +138,7 @@ struct DtRing {
             const int sl = (lo - 2) & (kDtT - 1);
             z(sl) = e.za; s(sl) = e.sa; v(sl) = va;
             sk = e.sb; vk = vb;
-            zk = quad_isect<R>(a, b, va, vb, e.sa, e.sb);   // as computed when entry lo-1 was pushed onto entry lo-2
+            zk = BZ ? quad_isect<R, true>(a, b, va, vb, e.sa, e.sb) : quad_isect<R, false>(a, b, va, vb, e.sa, e.sb);   // as computed when entry lo-1 was pushed onto entry lo-2
             lo -= 2;
         }
     }
@@ -141,7 +152,7 @@ struct DtRing {
 
 // AUX: the read-out additionally streams an int chunk per output chunk (prefetched one chunk ahead, q
 // descending) and hands it to `store` -- the columns pass uses it to carry the rows pass's pointers along.
-template <typename R, bool AUX, class LoadChunk, class StoreChunk, class AuxChunk>
+template <typename R, bool AUX, bool BZ, class LoadChunk, class StoreChunk, class AuxChunk>
 __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store,
                                           AuxChunk aux)
 {
@@ -159,12 +170,12 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
             if (q >= 1 && q < N) {
                 const R sq = cur[i];
                 DT_STAT(0);
-                R s = quad_isect<R>(a, b, vk, q, sk, sq);
+                R s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
                 while (s <= zk && k > 0) {
                     DT_STAT(1);
                     --k;
-                    ring.pop(k, zk, sk, vk);
-                    s = quad_isect<R>(a, b, vk, q, sk, sq);
+                    ring.template pop<BZ>(k, zk, sk, vk);
+                    s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
                 }
                 ring.push_below(k, zk, sk, vk);
                 ++k;
@@ -195,9 +206,9 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
                 while (!(zk < osf)) {   // z[0] = -inf ends the walk
                     DT_STAT(2);
                     --k;
-                    ring.pop(k, zk, sk, vk);
+                    ring.template pop<BZ>(k, zk, sk, vk);
                 }
-                out[i] = quad_val<R>(a, b, os0 + q - vk, sk);
+                out[i] = quad_val<R, BZ>(a, b, os0 + q - vk, sk);
                 ptr[i] = vk;
             }
         }
@@ -218,7 +229,7 @@ static_assert(kDtCH % 8 == 0, "the columns pass reads its int16 pointers 8 at a 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
 // RH: the responses are fp16 (PBD_CONV_MFMA_F16); a template parameter so that the default kernels carry none of it
 // PT: element type of the position planes (uint8_t when no map side exceeds 256, else int16_t)
-template <typename R, bool RH, typename PT>
+template <typename R, bool RH, typename PT, bool BZ>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
             if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (PT)ptr[i]; }
     };
     auto noaux = [](int, int *) {};
-    dt_stream<R, false>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
+    dt_stream<R, false, BZ>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
 }
 
 void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
@@ -293,18 +304,19 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
     if (p.JG == 0 || p.nrows_flat == 0) return;
     const int nwv = (p.nrows_flat + 63) / 64;
     dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
-#define PBD_ROWS(PT)                                                                                              \
-    do {                                                                                                          \
-        if (f64) hipLaunchKernelGGL((k_dt_rows<double, false, PT>), grid, dim3(64 * kDtWaves), 0, s, p);          \
-        else if (p.resp_half) hipLaunchKernelGGL((k_dt_rows<float, true, PT>), grid, dim3(64 * kDtWaves), 0, s, p); \
-        else hipLaunchKernelGGL((k_dt_rows<float, false, PT>), grid, dim3(64 * kDtWaves), 0, s, p);               \
+#define PBD_ROWS(PT, BZ)                                                                                              \
+    do {                                                                                                              \
+        if (f64) hipLaunchKernelGGL((k_dt_rows<double, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);          \
+        else if (p.resp_half) hipLaunchKernelGGL((k_dt_rows<float, true, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p); \
+        else hipLaunchKernelGGL((k_dt_rows<float, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);               \
     } while (0)
-    if (p.ptr8) PBD_ROWS(uint8_t); else PBD_ROWS(int16_t);
+    if (p.ptr8) { if (p.bz_x) PBD_ROWS(uint8_t, true); else PBD_ROWS(uint8_t, false); }
+    else { if (p.bz_x) PBD_ROWS(int16_t, true); else PBD_ROWS(int16_t, false); }
 #undef PBD_ROWS
 }
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
-template <typename R, typename PT>
+template <typename R, typename PT, bool BZ>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
 {
     const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // longest columns first, as in the rows pass
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
                 ixr[(size_t)(q0 + i) * W] = (PT)ix[i];
             }
     };
-    dt_stream<R, true>(H, job.ay, job.by, job.osy, ring, load, store, aux);
+    dt_stream<R, true, BZ>(H, job.ay, job.by, job.osy, ring, load, store, aux);
 }
 
 void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
@@ -376,13 +388,14 @@ void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
     if (p.JG == 0 || p.ncols_flat == 0) return;
     const int nwv = (p.ncols_flat + 63) / 64;
     dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
-    if (p.ptr8) {
-        if (f64) hipLaunchKernelGGL((k_dt_cols<double, uint8_t>), grid, dim3(64 * kDtWaves), 0, s, p);
-        else hipLaunchKernelGGL((k_dt_cols<float, uint8_t>), grid, dim3(64 * kDtWaves), 0, s, p);
-    } else {
-        if (f64) hipLaunchKernelGGL((k_dt_cols<double, int16_t>), grid, dim3(64 * kDtWaves), 0, s, p);
-        else hipLaunchKernelGGL((k_dt_cols<float, int16_t>), grid, dim3(64 * kDtWaves), 0, s, p);
-    }
+#define PBD_COLS(PT, BZ)                                                                                   \
+    do {                                                                                                   \
+        if (f64) hipLaunchKernelGGL((k_dt_cols<double, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);      \
+        else hipLaunchKernelGGL((k_dt_cols<float, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);           \
+    } while (0)
+    if (p.ptr8) { if (p.bz_y) PBD_COLS(uint8_t, true); else PBD_COLS(uint8_t, false); }
+    else { if (p.bz_y) PBD_COLS(int16_t, true); else PBD_COLS(int16_t, false); }
+#undef PBD_COLS
 }
 
 // ---- combine: thread = 4 consecutive cells of one level, one PARENT part (block.y) ---------------------
