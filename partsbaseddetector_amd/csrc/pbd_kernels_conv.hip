@@ -235,8 +235,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #undef PBD_PIN
         // a full group (all but possibly the last) stores without per-filter branches: one block of 8
         // independent stores per row
+        // the store addresses are formed here, after the channel loop: hoisted above it they would be carried through the
+        // loop in scratch (13 spilled 64-bit pointers per lane, 1 GB of scratch writes per 64-frame launch)
+        float *respg = resp;
+        asm volatile("" : "+v"(respg));
         if (g * Q + QL <= p.nf && p.fmap == nullptr) {
-            float *rg = resp + (size_t)(g * Q) * HW;
+            float *rg = respg + (size_t)(g * Q) * HW;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
                 if (x < W && y + pp < H) {
@@ -251,7 +255,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 #pragma unroll
                     for (int q = 0; q < QL; ++q) {
                         const int f = g * Q + q;
-                        if (f < p.nf) resp[(size_t)(p.fmap ? p.fmap[f] : f) * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
+                        if (f < p.nf) respg[(size_t)(p.fmap ? p.fmap[f] : f) * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
                     }
                 }
             }
