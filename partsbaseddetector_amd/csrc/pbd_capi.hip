@@ -224,6 +224,7 @@ struct pbd_handle {
     int cur_depth = kDepth8U;        // image depth of the frames being processed (set by the entry point)
     int shard_rank = 0, shard_world = 1;   // level sharding of single frames over several GPUs (pbd_set_level_shard)
     bool have_features = false, have_resp = false, have_dp = false;
+    bool feat_c31_zero = false;      // h->feat was written by the HOG kernels (channel 31 = 0), not uploaded by the caller
 
     // workspace
     DevBuf frames, pyr, gmag, gori, hist, norm, feat, resp, acc, Ix, Iy, Ik, rootv, rooti;
@@ -971,6 +972,7 @@ void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int cn, int f
         ProfScope ps(h, PBD_K_HOG_FEAT, st);
         launch_hog_feat(hp, nb, h->f64, st);
     }
+    h->feat_c31_zero = true;
 }
 
 int alloc_conv(pbd_handle *h, Plan &P, int nframes)
@@ -990,6 +992,7 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     cp.cell_per_frame = P.cell_per_frame;
     cp.feat = h->feat.p; cp.resp = h->resp.p;
     cp.fma = h->cfg.conv_mode == PBD_CONV_FMA;
+    cp.c31_zero = h->feat_c31_zero ? 1 : 0;
     ProfScope ps(h, PBD_K_CONV, st);
     for (const pbd_handle::ConvClass &C : h->conv_classes) {     // one launch per filter size (one class in every known model)
         cp.nf = C.nf; cp.Fpad = C.Fpad; cp.ksize = C.K; cp.wts = C.wts.p; cp.fmap = C.fmap.d;
@@ -1501,6 +1504,7 @@ int pbd_conv_pdf(pbd_handle *h, int nlevels, const void *const *feat, const int 
                                             hipMemcpyHostToDevice, h->stream));
         }
         h->cur = P; h->cur_frames = 1; h->have_features = true; h->have_resp = h->have_dp = false;
+        h->feat_c31_zero = false;
         if ((rc = run_conv(h, *P, 1)) != PBD_OK) return rc;
         std::vector<uint16_t> halfbuf;
         for (int l = 0; l < nlevels; ++l) {

@@ -150,6 +150,7 @@ struct ConvParams {
     int nf, Fpad, ksize;          // this launch: filters of one size class, padded to kConvQ, their size
     const int *fmap;              // class-local filter index -> response plane (NULL: identity, the single-class case)
     int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
+    int c31_zero;                 // the features come from this library's HOG: channel 31 is 0 in every cell of the image
     int frame0;
     long long cell_per_frame;
     const void *feat;             // R [frames][cell_per_frame*32]
