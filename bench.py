@@ -200,7 +200,8 @@ def main():
         roofline, roof_all = None, []
         traffic_tab = {}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        # the counters were collected on the default workload (64 frames of 640x480): other shapes carry no traffic figure
+        if os.path.exists(tf) and (B, rows, cols) == (64, 480, 640):
             try:
                 traffic_tab = json.load(open(tf))
             except Exception:
