@@ -133,14 +133,24 @@ def main():
 
     gatherer = pdist.CandidateGatherer(stride, cap_g, dev if args.backend == "nccl" else "cpu") if world > 1 else None
 
+    gathered = [0]
+
+    def drain():
+        if gatherer is not None and gatherer.pending:
+            rec = gatherer.finish(root_only=True)                                      # rank 0 holds the whole list
+            gathered[0] = len(rec) if rec is not None else 0
+
     def step():
+        # the candidate lists of batch k-1 are collected while batch k computes: begin() only packs the payload and issues
+        # the H2D copy and the (asynchronous) collective, finish() is called one step later, when it has long completed
         buf, n = det.detect_batch_device(d_frames.data_ptr(), B, rows, cols, cn, raw=True)
         if world > 1:
-            rec = gatherer.gather(buf, n, frame_offset=rank * B, root_only=True)      # rank 0 holds the whole list
-            return len(rec) if rec is not None else n
+            drain()
+            gatherer.begin(buf, n, frame_offset=rank * B)
         return n
 
     def sync():
+        drain()                                              # every issued gather is finished inside the timed region
         det.hd.check(det.hd.lib.pbd_synchronize(det.hd.h))
         torch.cuda.synchronize()
         if world > 1:
@@ -339,13 +349,14 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{3 if (rows, cols) == (1080, 1920) else 2}]: synthetic person model (26 parts x 6 mixtures = 156 filters "
                                    f"5x5x32), batch of {B} {cols}x{rows} frames per GPU, full HOG+conv+DT/DP+argmin on GPU",
-                       "frames_per_gpu_per_step": B, "conv_mode": args.conv_mode, "candidates_last_step": int(ncand),
+                       "frames_per_gpu_per_step": B, "conv_mode": args.conv_mode, "candidates_last_step": int(gathered[0] if world > 1 else ncand),
                        "parallelism": f"frames sharded over {world} GPU(s), RCCL all_gather of candidates",
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": dist.get_backend() if world > 1 else None,
                        "rank_ms_per_step": [round(v, 3) for v in rank_ms],
                        "gather": ({"collectives_per_step": gatherer.collectives / max(args.steps + args.warmup, 1),
-                                   "capacity_records": gatherer.cap, "grown": gatherer.grown} if gatherer else None)},
+                                   "capacity_records": gatherer.cap, "grown": gatherer.grown,
+                                   "overlap": "the collective of batch k runs under the kernels of batch k+1 (begin / finish one step apart)"} if gatherer else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": stage_ms,
             "roofline_all": roof_all,
             ("fast_mode" if args.conv_mode == "exact" else "exact_mode"): other_mode, "agreement": agreement,

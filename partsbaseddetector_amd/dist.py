@@ -80,6 +80,7 @@ class CandidateGatherer:
         self.collectives = 0          # all_gather calls issued so far (tests / bench: 1 per step in steady state)
         self.grown = 0                # how often the buffers had to grow
         self._copy_done = None        # event after the last H2D copy out of host_send (cuda only)
+        self._pending = None          # (work handle, true count, records beyond the capacity) between begin() and finish()
         self._alloc(max(int(cap), 1))
 
     def _alloc(self, cap: int):
@@ -98,34 +99,68 @@ class CandidateGatherer:
             self._copy_done.synchronize()
             self._copy_done = None
 
-    def gather(self, buf: np.ndarray, n: int, frame_offset: int, root_only: bool = False):
+    # ---- the gather in two halves, so that a caller can put the next batch's compute between them -------------------
+    # begin(): pack + H2D + the collective, issued asynchronously (`async_op=True`: RCCL runs it on its own stream next
+    # to the detection kernels, gloo on its worker threads); finish(): read the counts, grow-and-repeat on overflow,
+    # copy the records out.  One collective per batch, every rank issues them in the same order, and a finish() always
+    # precedes the next begin(), so the buffers are never rewritten under a collective in flight.
+    def begin(self, buf: np.ndarray, n: int, frame_offset: int):
+        if self._pending is not None:
+            raise RuntimeError("CandidateGatherer.begin(): the previous gather was not finished")
         n, stride = int(n), self.stride
-        while True:
-            self._wait_host_send_free()
+        self._wait_host_send_free()
+        m = min(n, self.cap)
+        hs = self.host_send.numpy()
+        hs[0] = n                                         # the TRUE count, also when it does not fit
+        if m:
+            rec = hs[1:1 + m * stride].reshape(m, stride)
+            rec[:] = buf[: m * stride].reshape(m, stride)
+            rec[:, 0] += frame_offset
+        # the caller's buffer is free again after this call; records beyond the capacity are kept for the repeat
+        spill = None
+        if n > m:
+            spill = np.array(buf[m * stride: n * stride], np.int32).reshape(n - m, stride)
+            spill[:, 0] += frame_offset
+        work = None
+        if self.world > 1:
+            # only the used prefix crosses PCIe; the collective moves the fixed-size payload
+            self.dev_send[: 1 + m * stride].copy_(self.host_send[: 1 + m * stride], non_blocking=True)
+            if self.device.type == "cuda":
+                self._copy_done = self.torch.cuda.Event()
+                self._copy_done.record(self.torch.cuda.current_stream(self.device))
+            work = self.dist.all_gather_into_tensor(self.dev_recv, self.dev_send, async_op=True)
+            self.collectives += 1
+        self._pending = (work, n, spill)
+
+    @property
+    def pending(self) -> bool:
+        return self._pending is not None
+
+    def finish(self, root_only: bool = False):
+        if self._pending is None:
+            raise RuntimeError("CandidateGatherer.finish(): no gather in flight")
+        work, n, spill = self._pending
+        self._pending = None
+        stride = self.stride
+        hs = self.host_send.numpy()
+        if self.world == 1:
+            counts = np.array([n])
+        else:
+            work.wait()
+            counts = self.dev_recv[:: self.n].cpu().numpy()          # world ints, read by EVERY rank
+        need = int(counts.max())
+        if need > self.cap:
+            # some rank did not fit: every rank sees that, grows to the same capacity and repeats the collective with its
+            # own records (global frame ids already applied) -- synchronously, this is the rare path
             m = min(n, self.cap)
-            hs = self.host_send.numpy()
-            hs[0] = n                                     # the TRUE count, also when it does not fit
-            if m:
-                rec = hs[1:1 + m * stride].reshape(m, stride)
-                rec[:] = buf[: m * stride].reshape(m, stride)
-                rec[:, 0] += frame_offset
-            if self.world == 1:
-                counts = np.array([n])
-            else:
-                # only the used prefix crosses PCIe; the collective moves the fixed-size payload
-                self.dev_send[: 1 + m * stride].copy_(self.host_send[: 1 + m * stride], non_blocking=True)
-                if self.device.type == "cuda":
-                    self._copy_done = self.torch.cuda.Event()
-                    self._copy_done.record(self.torch.cuda.current_stream(self.device))
-                self.dist.all_gather_into_tensor(self.dev_recv, self.dev_send)
-                self.collectives += 1
-                counts = self.dev_recv[:: self.n].cpu().numpy()      # world ints, read by EVERY rank
-            need = int(counts.max())
-            if need <= self.cap:
-                break
+            mine = hs[1:1 + m * stride].reshape(m, stride).copy()
+            if spill is not None:
+                mine = np.concatenate([mine, spill], axis=0)
             self._wait_host_send_free()
-            self._alloc(_grown(need))                     # same decision on every rank; repeat the collective
+            self._alloc(_grown(need))
             self.grown += 1
+            self.begin(mine.ravel(), n, 0)
+            return self.finish(root_only)
         if self.world == 1:
             return hs[1:1 + n * stride].reshape(n, stride).copy()
         if root_only and self.rank != 0:
@@ -141,6 +176,11 @@ class CandidateGatherer:
         if not parts:
             return np.zeros((0, stride), np.int32)
         return np.concatenate([p.numpy().reshape(-1, stride) for p in parts], axis=0)
+
+    def gather(self, buf: np.ndarray, n: int, frame_offset: int, root_only: bool = False):
+        """begin() + finish(): the synchronous form."""
+        self.begin(buf, n, frame_offset)
+        return self.finish(root_only)
 
 
 def gather_candidates(buf: np.ndarray, n: int, stride: int, cap: int, frame_offset: int, device) -> np.ndarray:

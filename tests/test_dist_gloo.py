@@ -191,3 +191,62 @@ def test_gatherer_overflow_grows_instead_of_raising():
         want_idx = np.concatenate([np.arange(c) for c in counts])
         assert np.array_equal(rec[:, 3], want_idx)
         assert np.array_equal(rec[:, 0], want_idx % 8 + 8 * want_rank)      # frame ids made global
+
+
+def _pipelined_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from partsbaseddetector_amd import dist as pd
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        stride = 12
+        g = pd.CandidateGatherer(stride, cap=16, device="cpu")
+        out = []
+        buf = np.zeros(64 * stride, np.int32)           # ONE buffer, rewritten every step like the detector's
+        # the bench's order: detect(k) ; finish(k-1) ; begin(k).  Step 2 overflows on rank 1 (40 > 16 records).
+        counts = [(3, 5), (7, 2), (4, 40), (6, 6)]
+        for step, c in enumerate(counts):
+            n = c[rank]
+            r = buf[: n * stride].reshape(n, stride)
+            r[:] = 1000 * step + 100 * rank
+            r[:, 0] = np.arange(n)
+            r[:, 1] = np.arange(n)
+            if g.pending:
+                out.append(g.finish(root_only=True))
+            g.begin(buf, n, frame_offset=50 * rank)
+            buf[:] = -1                                   # the caller's buffer is free after begin()
+        out.append(g.finish(root_only=True))
+        assert not g.pending
+        q.put((rank, out, g.collectives, g.grown))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gatherer_begin_finish_pipelined_with_overflow():
+    """begin() / finish() one step apart (the collective of batch k runs under the compute of batch k+1): same records
+    as the synchronous form, the caller's buffer may be rewritten right after begin(), an overflow is repaired in the
+    finish() that discovers it, and every rank issues the same number of collectives."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, ncoll, grown = q.get(timeout=180)
+        res[rank] = (out, ncoll, grown)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    stride = 12
+    counts = [(3, 5), (7, 2), (4, 40), (6, 6)]
+    assert res[0][1] == res[1][1] == 5 and res[0][2] == res[1][2] == 1      # 4 steps + one repeat; grown once
+    assert all(o is None for o in res[1][0])                                   # root_only
+    for step, c in enumerate(counts):
+        rec = res[0][0][step]
+        assert rec.shape == (sum(c), stride)
+        want_frame = np.concatenate([np.arange(c[0]), np.arange(c[1]) + 50])
+        assert np.array_equal(rec[:, 0], want_frame)
+        assert np.array_equal(rec[:, 1], np.concatenate([np.arange(c[0]), np.arange(c[1])]))
+        assert np.array_equal(rec[:, 2], np.concatenate([np.full(c[0], 1000 * step), np.full(c[1], 1000 * step + 100)]))
