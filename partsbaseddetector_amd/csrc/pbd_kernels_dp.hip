@@ -87,7 +87,12 @@ static_assert(sizeof(StkPairT<float>) == kStkPairF32 && sizeof(StkPairT<double>)
 #ifndef PBD_DT_CH
 #define PBD_DT_CH 16
 #endif
-constexpr int kDtCH = PBD_DT_CH;   // elements per streamed chunk (multiple of 4)
+constexpr int kDtCH = PBD_DT_CH;   // elements per streamed chunk of the rows pass (multiple of 4)
+#ifndef PBD_DT_CHC
+#define PBD_DT_CHC 8
+#endif
+constexpr int kDtCHC = PBD_DT_CHC;  // ... of the columns pass, which also carries the rows pass's pointers: a chunk of 8 keeps it at
+                                    // 5 waves per SIMD instead of 4 (columns pass -4 %, while the rows pass prefers 16)
 #ifndef PBD_DT_WAVES
 #define PBD_DT_WAVES 1
 #endif
@@ -152,11 +157,10 @@ struct DtRing {
 
 // AUX: the read-out additionally streams an int chunk per output chunk (prefetched one chunk ahead, q
 // descending) and hands it to `store` -- the columns pass uses it to carry the rows pass's pointers along.
-template <typename R, bool AUX, bool BZ, class LoadChunk, class StoreChunk, class AuxChunk>
+template <typename R, bool AUX, bool BZ, int CH, class LoadChunk, class StoreChunk, class AuxChunk>
 __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store,
                                           AuxChunk aux)
 {
-    constexpr int CH = kDtCH;
     R cur[CH], nxt[CH];
     load(0, cur);
     int k = 0, vk = 0;
@@ -223,8 +227,8 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef short v8s_u __attribute__((ext_vector_type(8), aligned(2)));
 typedef _Float16 v8h_u __attribute__((ext_vector_type(8), aligned(2)));
-typedef unsigned char vchb_u __attribute__((ext_vector_type(PBD_DT_CH), aligned(1)));
-static_assert(kDtCH % 8 == 0, "the columns pass reads its int16 pointers 8 at a time");
+typedef unsigned char vchb_u __attribute__((ext_vector_type(PBD_DT_CHC), aligned(1)));
+static_assert(kDtCHC % 8 == 0 && kDtCH % 8 == 0, "int16 pointers and fp16 responses are read 8 at a time");
 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
 // RH: the responses are fp16 (PBD_CONV_MFMA_F16); a template parameter so that the default kernels carry none of it
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
             if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (PT)ptr[i]; }
     };
     auto noaux = [](int, int *) {};
-    dt_stream<R, false, BZ>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
+    dt_stream<R, false, BZ, kDtCH>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
 }
 
 void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
@@ -340,27 +344,27 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
                                          ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane, job.ay, job.by);
     auto load = [&](int q0, R *buf) {
-        if (sizeof(R) == 4 && q0 + kDtCH <= H) {
+        if (sizeof(R) == 4 && q0 + kDtCHC <= H) {
             const float *srcf = reinterpret_cast<const float *>(tmpT);
 #pragma unroll
-            for (int v = 0; v < kDtCH / 4; ++v) {
+            for (int v = 0; v < kDtCHC / 4; ++v) {
                 const v4f_u a0 = *reinterpret_cast<const v4f_u *>(srcf + q0 + 4 * v);
                 buf[4 * v] = a0.x; buf[4 * v + 1] = a0.y; buf[4 * v + 2] = a0.z; buf[4 * v + 3] = a0.w;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? tmpT[q0 + i] : (R)0;
+            for (int i = 0; i < kDtCHC; ++i) buf[i] = (q0 + i < H) ? tmpT[q0 + i] : (R)0;
         }
     };
     auto aux = [&](int q0, int *buf) {      // the rows pass's pointers of this column
-        if (q0 + kDtCH <= H) {
+        if (q0 + kDtCHC <= H) {
             if constexpr (sizeof(PT) == 1) {
                 const vchb_u a0 = *reinterpret_cast<const vchb_u *>(ixT + q0);   // one load per chunk of uint8 positions
 #pragma unroll
-                for (int e = 0; e < kDtCH; ++e) buf[e] = a0[e];
+                for (int e = 0; e < kDtCHC; ++e) buf[e] = a0[e];
             } else {
 #pragma unroll
-                for (int v = 0; v < kDtCH / 8; ++v) {
+                for (int v = 0; v < kDtCHC / 8; ++v) {
                     const v8s_u a0 = *reinterpret_cast<const v8s_u *>(ixT + q0 + 8 * v);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) buf[8 * v + e] = a0[e];
@@ -368,19 +372,19 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < kDtCH; ++i) buf[i] = (q0 + i < H) ? ixT[q0 + i] : 0;
+            for (int i = 0; i < kDtCHC; ++i) buf[i] = (q0 + i < H) ? ixT[q0 + i] : 0;
         }
     };
     auto store = [&](int q0, const R *out, const int *ptr, const int *ix) {
 #pragma unroll
-        for (int i = 0; i < kDtCH; ++i)
+        for (int i = 0; i < kDtCHC; ++i)
             if (q0 + i < H) {
                 dt[(size_t)(q0 + i) * W] = out[i];
                 iyr[(size_t)(q0 + i) * W] = (PT)ptr[i];
                 ixr[(size_t)(q0 + i) * W] = (PT)ix[i];
             }
     };
-    dt_stream<R, true, BZ>(H, job.ay, job.by, job.osy, ring, load, store, aux);
+    dt_stream<R, true, BZ, kDtCHC>(H, job.ay, job.by, job.osy, ring, load, store, aux);
 }
 
 void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
