@@ -103,7 +103,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
     const bool skip31 = !FMA && p.c31_zero && tile.y0 >= a && tile.x0 >= a && tile.y0 + TH + a <= H && tile.x0 + TW + a <= W;
     // wave-private weight slice, 16-byte aligned
     float *wbuf = sm + ((32 * PLANE + 3) & ~3) + wave * (2 * WLANES * 4);
-    const bool wl = lane < WLANES;
+    // lanes past the last 16-byte piece of the 800-byte weight block repeat the last piece (same address, same data): the
+    // staging is then branch-free and the channel loop stays ONE basic block -- values that cross a block boundary reach the
+    // packed multiplies as lone 32-bit registers and are copied into both halves of a fresh pair first
+    const int wlane = lane < WLANES ? lane : WLANES - 1;
 
     // filter groups are handed out dynamically: the 2 x NW waves of the resident workgroups do not spread
     // evenly over the 4 SIMDs, so waves on the less loaded SIMDs take more groups
@@ -111,9 +114,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
     // 8 + 4: the half group runs half the packed operations instead of multiplying zeros -- 2 % of the launch)
     auto run_group = [&](auto ql_tag, const int g) {
         constexpr int QL = decltype(ql_tag)::value, QH = QL / 2, NWV = QL / 4;
-        const v4f *wsrc = reinterpret_cast<const v4f *>(wts + (size_t)g * 32 * WCH) + lane;
-        v4f wreg = wl ? wsrc[0] : v4f{0.f, 0.f, 0.f, 0.f};
-        if (wl) *reinterpret_cast<v4f *>(wbuf + lane * 4) = wreg;
+        const v4f *wsrc = reinterpret_cast<const v4f *>(wts + (size_t)g * 32 * WCH) + wlane;
+        v4f wreg = wsrc[0];
+        *reinterpret_cast<v4f *>(wbuf + wlane * 4) = wreg;
         v2f r[P][QH];
 #pragma unroll
         for (int pp = 0; pp < P; ++pp)
@@ -217,21 +220,21 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
         for (int c = 0; c < 32; c += 2) {
             const int c2 = min(c + 2, 31);
             // ---- channel c: weights slice 0; channel c+1's weights travel HBM -> wreg -> slice 1
-            if (wl) wreg = wsrc[(size_t)(c + 1) * (WCH / 4)];
+            wreg = wsrc[(size_t)(c + 1) * (WCH / 4)];
             PBD_STAGE(load_row(c, 4); load_w(1, c, 1), 0, 0);
             PBD_STAGE(load_row(c, 5); load_w(0, c, 2), 1, 1);
             PBD_STAGE(load_row(c, 6); load_w(1, c, 3), 0, 2);
-            if (wl) *reinterpret_cast<v4f *>(wbuf + WLANES * 4 + lane * 4) = wreg;
+            *reinterpret_cast<v4f *>(wbuf + WLANES * 4 + wlane * 4) = wreg;
             PBD_STAGE(load_row(c, 7); load_w(0, c, 4), 1, 3);
             PBD_STAGE(load_row(c + 1, 0); load_row(c + 1, 1); load_row(c + 1, 2); load_row(c + 1, 3); load_w(1, c + 1, 0), 0, 4);
             add_s();
             if (skip31 && c == 30) break;      // channel 31 is zero over the whole patch: its sum is +-0 and r + (+-0) == r
             // ---- channel c+1: slice 1; channel c+2 -> slice 0
-            if (wl) wreg = wsrc[(size_t)c2 * (WCH / 4)];
+            wreg = wsrc[(size_t)c2 * (WCH / 4)];
             PBD_STAGE(load_row(c + 1, 4); load_w(0, c + 1, 1), 1, 0);
             PBD_STAGE(load_row(c + 1, 5); load_w(1, c + 1, 2), 0, 1);
             PBD_STAGE(load_row(c + 1, 6); load_w(0, c + 1, 3), 1, 2);
-            if (wl) *reinterpret_cast<v4f *>(wbuf + lane * 4) = wreg;
+            *reinterpret_cast<v4f *>(wbuf + wlane * 4) = wreg;
             PBD_STAGE(load_row(c + 1, 7); load_w(1, c + 1, 4), 0, 3);
             PBD_STAGE(load_row(c2, 0); load_row(c2, 1); load_row(c2, 2); load_row(c2, 3); load_w(0, c2, 0), 1, 4);
             add_s();
