@@ -216,29 +216,43 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
         for (int rr = 0; rr < P; ++rr) load_row(0, rr);
         load_w(0, 0, 0);
         zero_s();                      // defined values for the first pin; every channel starts its own sum
+        // the first channel of a pair (weights slice 0; channel c+1's weights travel HBM -> wreg -> slice 1) ...
+#define PBD_EVEN_CHANNEL(c)                                                                                                       \
+    do {                                                                                                                          \
+        wreg = wsrc[(size_t)((c) + 1) * (WCH / 4)];                                                                               \
+        PBD_STAGE(load_row((c), 4); load_w(1, (c), 1), 0, 0);                                                                     \
+        PBD_STAGE(load_row((c), 5); load_w(0, (c), 2), 1, 1);                                                                     \
+        PBD_STAGE(load_row((c), 6); load_w(1, (c), 3), 0, 2);                                                                     \
+        *reinterpret_cast<v4f *>(wbuf + WLANES * 4 + wlane * 4) = wreg;                                                           \
+        PBD_STAGE(load_row((c), 7); load_w(0, (c), 4), 1, 3);                                                                     \
+        PBD_STAGE(load_row((c) + 1, 0); load_row((c) + 1, 1); load_row((c) + 1, 2); load_row((c) + 1, 3); load_w(1, (c) + 1, 0), 0, 4); \
+        add_s();                                                                                                                  \
+    } while (0)
+        // ... and the second (slice 1; channel c+2 -> slice 0)
+#define PBD_ODD_CHANNEL(c, c2)                                                                                                    \
+    do {                                                                                                                          \
+        wreg = wsrc[(size_t)(c2) * (WCH / 4)];                                                                                    \
+        PBD_STAGE(load_row((c) + 1, 4); load_w(0, (c) + 1, 1), 1, 0);                                                             \
+        PBD_STAGE(load_row((c) + 1, 5); load_w(1, (c) + 1, 2), 0, 1);                                                             \
+        PBD_STAGE(load_row((c) + 1, 6); load_w(0, (c) + 1, 3), 1, 2);                                                             \
+        *reinterpret_cast<v4f *>(wbuf + wlane * 4) = wreg;                                                                        \
+        PBD_STAGE(load_row((c) + 1, 7); load_w(1, (c) + 1, 4), 0, 3);                                                             \
+        PBD_STAGE(load_row((c2), 0); load_row((c2), 1); load_row((c2), 2); load_row((c2), 3); load_w(0, (c2), 0), 1, 4);          \
+        add_s();                                                                                                                  \
+    } while (0)
+        // channel 31 is zero over the whole patch of an interior tile (skip31): its sum is +-0 and r + (+-0) == r, so those
+        // tiles run 15 pairs and channel 30 alone -- as an epilogue, not as a break inside the loop body, which has to stay
+        // one basic block (see wlane)
+        const int cpairs = skip31 ? 30 : 32;
 #pragma clang loop unroll(disable)
-        for (int c = 0; c < 32; c += 2) {
+        for (int c = 0; c < cpairs; c += 2) {
             const int c2 = min(c + 2, 31);
-            // ---- channel c: weights slice 0; channel c+1's weights travel HBM -> wreg -> slice 1
-            wreg = wsrc[(size_t)(c + 1) * (WCH / 4)];
-            PBD_STAGE(load_row(c, 4); load_w(1, c, 1), 0, 0);
-            PBD_STAGE(load_row(c, 5); load_w(0, c, 2), 1, 1);
-            PBD_STAGE(load_row(c, 6); load_w(1, c, 3), 0, 2);
-            *reinterpret_cast<v4f *>(wbuf + WLANES * 4 + wlane * 4) = wreg;
-            PBD_STAGE(load_row(c, 7); load_w(0, c, 4), 1, 3);
-            PBD_STAGE(load_row(c + 1, 0); load_row(c + 1, 1); load_row(c + 1, 2); load_row(c + 1, 3); load_w(1, c + 1, 0), 0, 4);
-            add_s();
-            if (skip31 && c == 30) break;      // channel 31 is zero over the whole patch: its sum is +-0 and r + (+-0) == r
-            // ---- channel c+1: slice 1; channel c+2 -> slice 0
-            wreg = wsrc[(size_t)c2 * (WCH / 4)];
-            PBD_STAGE(load_row(c + 1, 4); load_w(0, c + 1, 1), 1, 0);
-            PBD_STAGE(load_row(c + 1, 5); load_w(1, c + 1, 2), 0, 1);
-            PBD_STAGE(load_row(c + 1, 6); load_w(0, c + 1, 3), 1, 2);
-            *reinterpret_cast<v4f *>(wbuf + wlane * 4) = wreg;
-            PBD_STAGE(load_row(c + 1, 7); load_w(1, c + 1, 4), 0, 3);
-            PBD_STAGE(load_row(c2, 0); load_row(c2, 1); load_row(c2, 2); load_row(c2, 3); load_w(0, c2, 0), 1, 4);
-            add_s();
+            PBD_EVEN_CHANNEL(c);
+            PBD_ODD_CHANNEL(c, c2);
         }
+        if (skip31) PBD_EVEN_CHANNEL(30);
+#undef PBD_EVEN_CHANNEL
+#undef PBD_ODD_CHANNEL
 #undef PBD_STAGE
 #undef PBD_PIN
         // a full group (all but possibly the last) stores without per-filter branches: one block of 8
