@@ -89,10 +89,9 @@ static_assert(sizeof(StkPairT<float>) == kStkPairF32 && sizeof(StkPairT<double>)
 #endif
 constexpr int kDtCH = PBD_DT_CH;   // elements per streamed chunk of the rows pass (multiple of 4)
 #ifndef PBD_DT_CHC
-#define PBD_DT_CHC 8
+#define PBD_DT_CHC 16
 #endif
-constexpr int kDtCHC = PBD_DT_CHC;  // ... of the columns pass, which also carries the rows pass's pointers: a chunk of 8 keeps it at
-                                    // 5 waves per SIMD instead of 4 (columns pass -4 %, while the rows pass prefers 16)
+constexpr int kDtCHC = PBD_DT_CHC;  // ... of the columns pass
 #ifndef PBD_DT_WAVES
 #define PBD_DT_WAVES 1
 #endif
@@ -155,9 +154,23 @@ struct DtRing {
     }
 };
 
+// Position chunks (the read-out's pointers, the columns pass's carried pointers) are kept EPW to a 32-bit register: 4 when the
+// positions are bytes (uint8 planes), 1 otherwise -- sixteen-element chunks then cost 4 registers instead of 16 each, which is
+// what keeps the columns pass at 6 waves per SIMD without shortening its chunks (8-element chunks were 4 % faster than
+// unpacked 16-element ones but moved 1.5x the bytes: every 128-byte line of a column was fetched four times instead of twice).
+template <int EPW> __device__ __forceinline__ int dt_get(const int *w, int i)
+{
+    return EPW == 1 ? w[i] : (int)(((unsigned)w[i / EPW] >> (8 * (i % EPW))) & 0xffu);
+}
+template <int EPW> __device__ __forceinline__ void dt_put(int *w, int i, int v)     // the word was zeroed before its first element
+{
+    if (EPW == 1) w[i] = v;
+    else w[i / EPW] |= v << (8 * (i % EPW));
+}
+
 // AUX: the read-out additionally streams an int chunk per output chunk (prefetched one chunk ahead, q
 // descending) and hands it to `store` -- the columns pass uses it to carry the rows pass's pointers along.
-template <typename R, bool AUX, bool BZ, int CH, class LoadChunk, class StoreChunk, class AuxChunk>
+template <typename R, bool AUX, bool BZ, int CH, int EPW, class LoadChunk, class StoreChunk, class AuxChunk>
 __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store,
                                           AuxChunk aux)
 {
@@ -191,18 +204,21 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
     }
     // read-out, q descending
     const int nch = (N + CH - 1) / CH;
-    int aux_cur[CH], aux_nxt[CH];
+    constexpr int NW = CH / EPW;
+    int aux_cur[NW], aux_nxt[NW];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) { aux_cur[i] = 0; aux_nxt[i] = 0; }
+    for (int i = 0; i < NW; ++i) { aux_cur[i] = 0; aux_nxt[i] = 0; }
     if (AUX) aux((nch - 1) * CH, aux_cur);
     for (int cidx = nch - 1; cidx >= 0; --cidx) {
         const int q0 = cidx * CH;
         if (AUX && cidx > 0) aux(q0 - CH, aux_nxt);
         R out[CH];
-        int ptr[CH];
+        int ptr[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) ptr[i] = 0;
 #pragma unroll
         for (int i = CH - 1; i >= 0; --i) {
-            out[i] = (R)0; ptr[i] = 0;
+            out[i] = (R)0;
             const int q = q0 + i;
             if (q < N) {
                 const R osf = (R)(os0 + q);
@@ -213,13 +229,13 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
                     ring.template pop<BZ>(k, zk, sk, vk);
                 }
                 out[i] = quad_val<R, BZ>(a, b, os0 + q - vk, sk);
-                ptr[i] = vk;
+                dt_put<EPW>(ptr, i, vk);
             }
         }
         store(q0, out, ptr, aux_cur);
         if (AUX) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) aux_cur[i] = aux_nxt[i];
+            for (int i = 0; i < NW; ++i) aux_cur[i] = aux_nxt[i];
         }
     }
 }
@@ -227,7 +243,7 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef short v8s_u __attribute__((ext_vector_type(8), aligned(2)));
 typedef _Float16 v8h_u __attribute__((ext_vector_type(8), aligned(2)));
-typedef unsigned char vchb_u __attribute__((ext_vector_type(PBD_DT_CHC), aligned(1)));
+typedef unsigned vchw_u __attribute__((ext_vector_type(PBD_DT_CHC / 4), aligned(1)));
 static_assert(kDtCHC % 8 == 0 && kDtCH % 8 == 0, "int16 pointers and fp16 responses are read 8 at a time");
 
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
@@ -236,6 +252,7 @@ static_assert(kDtCHC % 8 == 0 && kDtCH % 8 == 0, "int16 pointers and fp16 respon
 template <typename R, bool RH, typename PT, bool BZ>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
+    constexpr int EPW = sizeof(PT) == 1 ? 4 : 1;
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
     // the large levels are dispatched first and the tail of the launch is made of short ones
     const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -297,10 +314,10 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     auto store = [&](int q0, const R *out, const int *ptr, const int *) {
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i)
-            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (PT)ptr[i]; }
+            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (PT)dt_get<EPW>(ptr, i); }
     };
     auto noaux = [](int, int *) {};
-    dt_stream<R, false, BZ, kDtCH>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
+    dt_stream<R, false, BZ, kDtCH, EPW>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
 }
 
 void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
@@ -321,8 +338,10 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
 template <typename R, typename PT, bool BZ>
-__global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
+__global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(sizeof(PT) == 1 && sizeof(R) == 4 ? 6 : 1)))
+void k_dt_cols(DpParams p)
 {
+    constexpr int EPW = sizeof(PT) == 1 ? 4 : 1;
     const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // longest columns first, as in the rows pass
     const int cidx = wv * 64 + lane;
     if (cidx >= p.ncols_flat) return;
@@ -359,9 +378,9 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
     auto aux = [&](int q0, int *buf) {      // the rows pass's pointers of this column
         if (q0 + kDtCHC <= H) {
             if constexpr (sizeof(PT) == 1) {
-                const vchb_u a0 = *reinterpret_cast<const vchb_u *>(ixT + q0);   // one load per chunk of uint8 positions
+                const vchw_u a0 = *reinterpret_cast<const vchw_u *>(ixT + q0);   // one load per chunk of uint8 positions, kept packed
 #pragma unroll
-                for (int e = 0; e < kDtCHC; ++e) buf[e] = a0[e];
+                for (int e = 0; e < kDtCHC / 4; ++e) buf[e] = (int)a0[e];
             } else {
 #pragma unroll
                 for (int v = 0; v < kDtCHC / 8; ++v) {
@@ -372,7 +391,9 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < kDtCHC; ++i) buf[i] = (q0 + i < H) ? ixT[q0 + i] : 0;
+            for (int i = 0; i < kDtCHC / EPW; ++i) buf[i] = 0;
+#pragma unroll
+            for (int i = 0; i < kDtCHC; ++i) dt_put<EPW>(buf, i, (q0 + i < H) ? (int)ixT[q0 + i] : 0);
         }
     };
     auto store = [&](int q0, const R *out, const int *ptr, const int *ix) {
@@ -380,11 +401,11 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_cols(DpParams p)
         for (int i = 0; i < kDtCHC; ++i)
             if (q0 + i < H) {
                 dt[(size_t)(q0 + i) * W] = out[i];
-                iyr[(size_t)(q0 + i) * W] = (PT)ptr[i];
-                ixr[(size_t)(q0 + i) * W] = (PT)ix[i];
+                iyr[(size_t)(q0 + i) * W] = (PT)dt_get<EPW>(ptr, i);
+                ixr[(size_t)(q0 + i) * W] = (PT)dt_get<EPW>(ix, i);
             }
     };
-    dt_stream<R, true, BZ, kDtCHC>(H, job.ay, job.by, job.osy, ring, load, store, aux);
+    dt_stream<R, true, BZ, kDtCHC, EPW>(H, job.ay, job.by, job.osy, ring, load, store, aux);
 }
 
 void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
