@@ -465,7 +465,8 @@ __device__ __forceinline__ void store_cells(T *dst, int n, const T *src)
 
 // MAXM: compile-time bound on the mixtures per part of the model (register arrays are sized by it)
 template <typename R, int kCpt, int MAXM, bool RH, typename PT>
-__global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXM <= 6 && sizeof(R) == 4 ? 4 : 1)))
+void k_dp_combine(DpParams p)
 {
     constexpr int SUB = 4 / kCpt;   // threads per group of 4 cells
     const long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
     const int n = min(kCpt, HWi - local);
     int rowbase[kCpt];       // y * W of each cell
 #pragma unroll
-    for (int e = 0; e < kCpt; ++e) rowbase[e] = ((local + e) / W) * W;
+    for (int e = 0; e < kCpt; ++e) rowbase[e] = (min(local + e, HWi - 1) / W) * W;
     const R *resp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + local;
     const R *dtp = static_cast<const R *>(p.dt);
     const size_t gbase0 = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG;
@@ -532,7 +533,9 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
 #pragma unroll
         for (int mm = 0; mm < MAXM; ++mm) {
 #pragma unroll
-            for (int e = 0; e < kCpt; ++e) { dtv[mm][e] = (R)0; ixv[mm][e] = 0; }
+            // a mixture the child does not have scores -inf: it can never win the strict `>` below, so the selection loop
+            // needs no `mm < nmix` test (a uniform branch per candidate, i.e. 144 basic blocks per child with their copies)
+            for (int e = 0; e < kCpt; ++e) { dtv[mm][e] = -RealLimits<R>::inf(); ixv[mm][e] = 0; }
             if (mm < cd.nmix) {
                 load_cells<R, kCpt>(dtp + gbase + (size_t)mm * HW + local, n, dtv[mm]);
                 load_cells<PT, kCpt>(static_cast<const PT *>(p.IxRaw) + gbase + (size_t)mm * HW + local, n, ixv[mm]);
@@ -543,26 +546,33 @@ __global__ __launch_bounds__(256) void k_dp_combine(DpParams p)
             if (pm < cj.npar) {
                 PT oix[kCpt], oiy[kCpt];
                 uint8_t oik[kCpt];
+                R best[kCpt];
+                int bi[kCpt], ix[kCpt];
 #pragma unroll
-                for (int e = 0; e < kCpt; ++e) {
-                    R best;
-                    int bi = 0, ix = ixv[0][e];
-                    if (cd.nmix == 1) {
-                        best = dtv[0][e] + (R)bw[0][pm];
-                    } else {
-                        best = -RealLimits<R>::inf();
+                for (int e = 0; e < kCpt; ++e) { bi[e] = 0; ix[e] = ixv[0][e]; }
+                if (cd.nmix == 1) {     // K == 1 copies (Math::reduceMax)
+#pragma unroll
+                    for (int e = 0; e < kCpt; ++e) best[e] = dtv[0][e] + (R)bw[0][pm];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < kCpt; ++e) {
+                        best[e] = -RealLimits<R>::inf();
 #pragma unroll
                         for (int mm = 0; mm < MAXM; ++mm) {
-                            if (mm < cd.nmix) {
-                                const R wv = dtv[mm][e] + (R)bw[mm][pm];
-                                if (wv > best) { bi = mm; best = wv; ix = ixv[mm][e]; }
-                            }
+                            const R wv = dtv[mm][e] + (R)bw[mm][pm];
+                            const bool t = wv > best[e];
+                            best[e] = t ? wv : best[e];
+                            bi[e] = t ? mm : bi[e];
+                            ix[e] = t ? (int)ixv[mm][e] : ix[e];
                         }
                     }
-                    int iy = 0;
-                    if (e < n) iy = static_cast<const PT *>(p.IyRaw)[gbase + (size_t)bi * HW + rowbase[e] + ix];
-                    oix[e] = (PT)ix; oiy[e] = (PT)iy; oik[e] = (uint8_t)bi;
-                    accv[pm][e] = accv[pm][e] + best;
+                }
+#pragma unroll
+                for (int e = 0; e < kCpt; ++e) {
+                    // unconditional: cells past the end of the level (e >= n, never stored) gather from the last valid row
+                    const int iy = static_cast<const PT *>(p.IyRaw)[gbase + (size_t)bi[e] * HW + rowbase[e] + ix[e]];
+                    oix[e] = (PT)ix[e]; oiy[e] = (PT)iy; oik[e] = (uint8_t)bi[e];
+                    accv[pm][e] = accv[pm][e] + best[e];
                 }
                 const size_t o = pbase + (size_t)(cd.slot + pm) * HW;
                 store_cells<PT, kCpt>(static_cast<PT *>(p.Ix) + o, n, oix);
