@@ -1034,9 +1034,9 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     const size_t per_frame = cpf * std::max(h->JGmax, 1);
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
-    HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
+    HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16) + 32));            // + slack: the combine step reads whole cell groups
     HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * pes, 16) + 16));      // + slack: 16-byte chunk reads
-    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16)));
+    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16) + 32));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16)));
     HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkPairF64 : kStkPairF32), 16)));
     return PBD_OK;

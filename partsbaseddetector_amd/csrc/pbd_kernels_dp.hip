@@ -449,6 +449,15 @@ __device__ __forceinline__ void load_cells(const T *src, int n, T *dst)
         for (int e = 0; e < kCpt; ++e) dst[e] = (e < n) ? src[e] : (T)0;
     }
 }
+// the same without the test: the caller tolerates cells past the end of the level (they come from the next plane, the buffers
+// end in slack) because it never stores them -- one wide load instead of a divergent region per access
+template <typename T, int kCpt>
+__device__ __forceinline__ void load_cells_wide(const T *src, T *dst)
+{
+    const typename CellVec<T, kCpt>::type v = *reinterpret_cast<const typename CellVec<T, kCpt>::type *>(src);
+#pragma unroll
+    for (int e = 0; e < kCpt; ++e) dst[e] = (T)v[e];
+}
 template <typename T, int kCpt>
 __device__ __forceinline__ void store_cells(T *dst, int n, const T *src)
 {
@@ -537,8 +546,8 @@ void k_dp_combine(DpParams p)
             // needs no `mm < nmix` test (a uniform branch per candidate, i.e. 144 basic blocks per child with their copies)
             for (int e = 0; e < kCpt; ++e) { dtv[mm][e] = -RealLimits<R>::inf(); ixv[mm][e] = 0; }
             if (mm < cd.nmix) {
-                load_cells<R, kCpt>(dtp + gbase + (size_t)mm * HW + local, n, dtv[mm]);
-                load_cells<PT, kCpt>(static_cast<const PT *>(p.IxRaw) + gbase + (size_t)mm * HW + local, n, ixv[mm]);
+                load_cells_wide<R, kCpt>(dtp + gbase + (size_t)mm * HW + local, dtv[mm]);
+                load_cells_wide<PT, kCpt>(static_cast<const PT *>(p.IxRaw) + gbase + (size_t)mm * HW + local, ixv[mm]);
             }
         }
 #pragma unroll
@@ -569,8 +578,9 @@ void k_dp_combine(DpParams p)
                 }
 #pragma unroll
                 for (int e = 0; e < kCpt; ++e) {
-                    // unconditional: cells past the end of the level (e >= n, never stored) gather from the last valid row
-                    const int iy = static_cast<const PT *>(p.IyRaw)[gbase + (size_t)bi[e] * HW + rowbase[e] + ix[e]];
+                    // unconditional: cells past the end of the level (e >= n, never stored; their inputs are whatever follows the
+                    // level in the buffers) gather from column 0 of the last valid row
+                    const int iy = static_cast<const PT *>(p.IyRaw)[gbase + (size_t)bi[e] * HW + rowbase[e] + (e < n ? ix[e] : 0)];
                     oix[e] = (PT)ix[e]; oiy[e] = (PT)iy; oik[e] = (uint8_t)bi[e];
                     accv[pm][e] = accv[pm][e] + best[e];
                 }
