@@ -19,6 +19,8 @@
 // The 1e-4 score bar does NOT hold in this mode; tests report the error and the detection agreement.
 #include "pbd_internal.h"
 
+#include <type_traits>
+
 namespace pbd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -193,25 +195,31 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 
                 for (int v = 0; v < NV; ++v) wq[wj][v] = wsrc[(size_t)snext * kStep + v * 64];
             }
         }
-        // D layout (32x32): column = lane & 31 (pixel), row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) (filter)
+        // D layout (32x32): column = lane & 31 (pixel), row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) (filter).
+        // The 16 plane pointers of a lane are formed by additions from one base (the products f * HW were two full-width
+        // multiplies per store, and `f < F` a divergent region per store: more instructions than the fp16 mode's matrix work);
+        // the filter test is uniform for every M-tile but the last (m_full).
+        const bool m_full = pass * kMfmaFB + m * 32 + 32 <= p.F;
+        using RT = typename std::conditional<F16, _Float16, float>::type;
+        RT *rbase = reinterpret_cast<RT *>(respp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)f0 * HW;
 #pragma unroll
         for (int n = 0; n < NH; ++n) {
             const int q = (half * NH + n) * 32 + r;
             const int y = tile.y0 + q / TW, x = tile.x0 + q % TW;
             if (x < W && y < H) {
-                if constexpr (F16) {       // fp16 responses (BASELINE configs[4]): same element index, half the bytes
-                    _Float16 *rp = reinterpret_cast<_Float16 *>(respp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)y * W + x;
+                RT *rp = rbase + (size_t)y * W + x;
+                if (m_full) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int f = f0 + (e & 3) + 8 * (e >> 2);
-                        if (f < p.F) rp[(size_t)f * HW] = (_Float16)acc[n][e];
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        RT *rg = rp + (size_t)(8 * g4) * HW;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { *rg = (RT)acc[n][4 * g4 + e]; rg += HW; }
                     }
                 } else {
-                    float *rp = resp + (size_t)y * W + x;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int f = f0 + (e & 3) + 8 * (e >> 2);
-                        if (f < p.F) rp[(size_t)f * HW] = acc[n][e];
+                        const int fo = (e & 3) + 8 * (e >> 2);
+                        if (f0 + fo < p.F) rp[(size_t)fo * HW] = (RT)acc[n][e];
                     }
                 }
             }
