@@ -312,9 +312,14 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
         }
     };
     auto store = [&](int q0, const R *out, const int *ptr, const int *) {
+        // the element pointers advance by additions (a 64-bit multiply per store is a quarter-rate instruction)
+        R *tp = tmpT + (size_t)q0 * Hl;
+        PT *ip = ixT + (size_t)q0 * Hl;
 #pragma unroll
-        for (int i = 0; i < kDtCH; ++i)
-            if (q0 + i < N) { tmpT[(size_t)(q0 + i) * Hl] = out[i]; ixT[(size_t)(q0 + i) * Hl] = (PT)dt_get<EPW>(ptr, i); }
+        for (int i = 0; i < kDtCH; ++i) {
+            if (q0 + i < N) { *tp = out[i]; *ip = (PT)dt_get<EPW>(ptr, i); }
+            tp += Hl; ip += Hl;
+        }
     };
     auto noaux = [](int, int *) {};
     dt_stream<R, false, BZ, kDtCH, EPW>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
@@ -397,13 +402,17 @@ void k_dt_cols(DpParams p)
         }
     };
     auto store = [&](int q0, const R *out, const int *ptr, const int *ix) {
+        R *dp = dt + (size_t)q0 * W;
+        PT *yp = iyr + (size_t)q0 * W, *xp = ixr + (size_t)q0 * W;
 #pragma unroll
-        for (int i = 0; i < kDtCHC; ++i)
+        for (int i = 0; i < kDtCHC; ++i) {
             if (q0 + i < H) {
-                dt[(size_t)(q0 + i) * W] = out[i];
-                iyr[(size_t)(q0 + i) * W] = (PT)dt_get<EPW>(ptr, i);
-                ixr[(size_t)(q0 + i) * W] = (PT)dt_get<EPW>(ix, i);
+                *dp = out[i];
+                *yp = (PT)dt_get<EPW>(ptr, i);
+                *xp = (PT)dt_get<EPW>(ix, i);
             }
+            dp += W; yp += W; xp += W;
+        }
     };
     dt_stream<R, true, BZ, kDtCHC, EPW>(H, job.ay, job.by, job.osy, ring, load, store, aux);
 }

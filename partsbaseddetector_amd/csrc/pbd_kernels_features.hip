@@ -209,6 +209,12 @@ void launch_resize(const PyrParams &p, int nframes, long long npix, hipStream_t 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int len)
 {
+    // the taps reach at most two positions outside [0, len): for len >= 3 one reflection each way is the whole loop, as
+    // selects (the loop form cost a compare-and-branch pair per coordinate, ten per pixel)
+    if (len >= 3) {
+        p = p < 0 ? -p : p;
+        return p >= len ? 2 * len - 2 - p : p;
+    }
     if (len == 1) return 0;
     while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
     return p;
