@@ -160,12 +160,14 @@ struct DtRing {
 // unpacked 16-element ones but moved 1.5x the bytes: every 128-byte line of a column was fetched four times instead of twice).
 template <int EPW> __device__ __forceinline__ int dt_get(const int *w, int i)
 {
-    return EPW == 1 ? w[i] : (int)(((unsigned)w[i / EPW] >> (8 * (i % EPW))) & 0xffu);
+    constexpr int BITS = 32 / EPW;          // 8-bit fields (uint8 planes), 16-bit fields (int16 planes; positions are >= 0)
+    return EPW == 1 ? w[i] : (int)(((unsigned)w[i / EPW] >> (BITS * (i % EPW))) & ((1u << BITS) - 1u));
 }
 template <int EPW> __device__ __forceinline__ void dt_put(int *w, int i, int v)     // the word was zeroed before its first element
 {
+    constexpr int BITS = 32 / EPW;
     if (EPW == 1) w[i] = v;
-    else w[i / EPW] |= v << (8 * (i % EPW));
+    else w[i / EPW] |= v << (BITS * (i % EPW));
 }
 
 // AUX: the read-out additionally streams an int chunk per output chunk (prefetched one chunk ahead, q
@@ -252,7 +254,7 @@ static_assert(kDtCHC % 8 == 0 && kDtCH % 8 == 0, "int16 pointers and fp16 respon
 template <typename R, bool RH, typename PT, bool BZ>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
-    constexpr int EPW = sizeof(PT) == 1 ? 4 : 1;
+    constexpr int EPW = 4 / (int)sizeof(PT);
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
     // the large levels are dispatched first and the tail of the launch is made of short ones
     const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -343,10 +345,10 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
 template <typename R, typename PT, bool BZ>
-__global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(sizeof(PT) == 1 && sizeof(R) == 4 ? 6 : 1)))
+__global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? (sizeof(PT) == 1 ? 6 : 5) : 1)))
 void k_dt_cols(DpParams p)
 {
-    constexpr int EPW = sizeof(PT) == 1 ? 4 : 1;
+    constexpr int EPW = 4 / (int)sizeof(PT);
     const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // longest columns first, as in the rows pass
     const int cidx = wv * 64 + lane;
     if (cidx >= p.ncols_flat) return;
@@ -387,11 +389,12 @@ void k_dt_cols(DpParams p)
 #pragma unroll
                 for (int e = 0; e < kDtCHC / 4; ++e) buf[e] = (int)a0[e];
             } else {
+                typedef unsigned v4w_u __attribute__((ext_vector_type(4), aligned(2)));
 #pragma unroll
-                for (int v = 0; v < kDtCHC / 8; ++v) {
-                    const v8s_u a0 = *reinterpret_cast<const v8s_u *>(ixT + q0 + 8 * v);
+                for (int v = 0; v < kDtCHC / 8; ++v) {      // 8 int16 positions = 4 words, kept packed
+                    const v4w_u a0 = *reinterpret_cast<const v4w_u *>(ixT + q0 + 8 * v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) buf[8 * v + e] = a0[e];
+                    for (int e = 0; e < 4; ++e) buf[4 * v + e] = (int)a0[e];
                 }
             }
         } else {
