@@ -113,15 +113,15 @@ struct Plan {
     DevTable<ResizeTabY> d_taby;
     DevTable<ResizeTabXf> d_tabxf;   // the same mapping with float coefficients (16U / 32F / 64F images)
     DevTable<ResizeTabYf> d_tabyf;
-    DevTable<ConvTile> d_tiles, d_shaped, d_htiles;
-    int nshaped[3] = {0, 0, 0}, nhtiles = 0;
+    DevTable<ConvTile> d_tiles, d_shaped, d_shaped4, d_htiles;
+    int nshaped[3] = {0, 0, 0}, nshaped4[4] = {0, 0, 0, 0}, nhtiles = 0;
     DevTable<int> d_row2level, d_rowoff, d_col2level, d_coloff;
     DevTable<long long> d_stk_row_off, d_stk_col_off;
     long long stk_per_jf = 0;
     DevTable<float> d_scales;
     void release()
     {
-        d_lv.release(); d_tabx.release(); d_taby.release(); d_tabxf.release(); d_tabyf.release(); d_tiles.release(); d_shaped.release(); d_htiles.release();
+        d_lv.release(); d_tabx.release(); d_taby.release(); d_tabxf.release(); d_tabyf.release(); d_tiles.release(); d_shaped.release(); d_shaped4.release(); d_htiles.release();
         d_row2level.release(); d_rowoff.release(); d_col2level.release(); d_coloff.release(); d_scales.release();
         d_stk_row_off.release(); d_stk_col_off.release();
     }
@@ -337,7 +337,7 @@ hipError_t finish_plan_tables(Plan &P, int sbin)
 {
     // flat row / column lookup and conv tiles over the feature maps
     std::vector<int> row2level, rowoff(P.nlevels + 1, 0), col2level, coloff(P.nlevels + 1, 0);
-    std::vector<ConvTile> tiles, shaped[3], htiles;
+    std::vector<ConvTile> tiles, shaped[3], shaped4[4], htiles;
     P.quad_per_frame = 0;
     for (int l = 0; l < P.nlevels; ++l) {
         P.lv[l].quad_off = P.quad_per_frame;
@@ -353,6 +353,16 @@ hipError_t finish_plan_tables(Plan &P, int sbin)
             for (int y0 = 0; y0 < d.rows; y0 += kConvTH)
                 for (int x0 = 0; x0 < d.cols; x0 += kConvTW) tiles.push_back({l, y0, x0});
             cover_level(l, d.rows, d.cols, shaped);
+            // exact kernel: the same cover, or wrapped 64 x 4 tiles where those are fewer (levels at least 64 cells wide)
+            std::vector<ConvTile> lvl[3];
+            cover_level(l, d.rows, d.cols, lvl);
+            const long long npos = (long long)d.cols * ((d.rows + 3) / 4);
+            const long long nwrap = (npos + 63) / 64;
+            if (d.cols >= 64 && nwrap < (long long)(lvl[0].size() + lvl[1].size() + lvl[2].size())) {
+                for (long long t = 0; t < nwrap; ++t) shaped4[3].push_back({l, (int)(t * 64 / d.cols), (int)(t * 64 % d.cols)});
+            } else {
+                for (int k = 0; k < 3; ++k) shaped4[k].insert(shaped4[k].end(), lvl[k].begin(), lvl[k].end());
+            }
         }
     }
     {
@@ -385,12 +395,15 @@ hipError_t finish_plan_tables(Plan &P, int sbin)
     P.stk_per_jf = std::max(tot_r, tot_c);
     std::vector<ConvTile> all;
     for (int k = 0; k < 3; ++k) { P.nshaped[k] = (int)shaped[k].size(); all.insert(all.end(), shaped[k].begin(), shaped[k].end()); }
+    std::vector<ConvTile> all4;
+    for (int k = 0; k < 4; ++k) { P.nshaped4[k] = (int)shaped4[k].size(); all4.insert(all4.end(), shaped4[k].begin(), shaped4[k].end()); }
     hipError_t e;
     if ((e = P.d_stk_row_off.upload(srow)) != hipSuccess) return e;
     if ((e = P.d_stk_col_off.upload(scol)) != hipSuccess) return e;
     if ((e = P.d_lv.upload(P.lv)) != hipSuccess) return e;
     if ((e = P.d_tiles.upload(tiles)) != hipSuccess) return e;
     if ((e = P.d_shaped.upload(all)) != hipSuccess) return e;
+    if ((e = P.d_shaped4.upload(all4)) != hipSuccess) return e;
     if ((e = P.d_htiles.upload(htiles)) != hipSuccess) return e;
     if ((e = P.d_row2level.upload(row2level)) != hipSuccess) return e;
     if ((e = P.d_rowoff.upload(rowoff)) != hipSuccess) return e;
@@ -988,6 +1001,8 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     cp.lv = P.d_lv.d; cp.tiles = P.d_tiles.d; cp.ntiles = P.ntiles;
     cp.shaped = P.d_shaped.d;
     for (int k = 0; k < 3; ++k) cp.nshaped[k] = P.nshaped[k];
+    cp.shaped4 = P.d_shaped4.d;
+    for (int k = 0; k < 4; ++k) cp.nshaped4[k] = P.nshaped4[k];
     cp.F = h->F; cp.frame0 = f0;
     cp.cell_per_frame = P.cell_per_frame;
     cp.feat = h->feat.p; cp.resp = h->resp.p;

@@ -146,6 +146,11 @@ struct ConvParams {
     int ntiles;
     const ConvTile *shaped;       // mixed-shape tiling of the exact 5x5 kernel: 32x8 tiles, then 16x16, then 8x32
     int nshaped[3];
+    // the exact 5x5 kernel's own cover: the three shapes, then WRAPPED tiles (shape 3) -- 64 consecutive positions of the
+    // sequence "strip 0 (rows 0..3) left to right, strip 1, ..." of a level at least 64 cells wide; such a tile runs over the
+    // right edge into the next strip instead of leaving lanes idle there.  ConvTile::y0 = strip, x0 = first column
+    const ConvTile *shaped4;
+    int nshaped4[4];
     int F;                        // response planes per cell block (all filters of the bank)
     int nf, Fpad, ksize;          // this launch: filters of one size class, padded to kConvQ, their size
     const int *fmap;              // class-local filter index -> response plane (NULL: identity, the single-class case)

@@ -41,14 +41,18 @@ template <int K, bool FMA, int NW, int S>
 __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__restrict__ wts, const float *__restrict__ featp,
                                           float *__restrict__ respp, float *sm, int *next_g, const ConvTile tile)
 {
-    constexpr int TW = kConvTW >> S, TH = kConvTH << S, Q = kConvQ, P = 4;
+    // S = 3: a WRAPPED tile -- 64 consecutive positions of the level's strips of four rows, i.e. up to two segments: the rest
+    // of strip `tile.y0` from column `tile.x0`, then the beginning of the next strip.  Their haloed patches lie side by side
+    // in the same PH rows of LDS (PW = 64 + 2 (K - 1)), so the row pitch is uniform and the channel loop does not change.
+    constexpr bool WRAP = S == 3;
+    constexpr int TW = WRAP ? 64 : kConvTW >> S, TH = WRAP ? 4 : kConvTH << S, Q = kConvQ, P = 4;
     static_assert(TW * TH == 256 && TH % P == 0, "a wave of 64 lanes x 4 rows covers the tile");
-    constexpr int PW = TW + K - 1, PH = TH + K - 1;
+    constexpr int PW = WRAP ? TW + 2 * (K - 1) : TW + K - 1, PH = TH + K - 1;
     constexpr int PLANE = (PH * PW) | 1;   // odd plane stride: conflict-free staging writes
     constexpr int WCH = K * K * Q;         // weights of one (group, channel)
     constexpr int WLANES = (WCH + 3) / 4;  // lanes that stage 16 bytes each
     static_assert(WLANES <= 64, "one staging instruction per wave");
-    static_assert(32 * PLANE + 3 + NW * 2 * WLANES * 4 <= 32 * 433 + 3 + NW * 2 * WLANES * 4, "LDS sized for the largest shape");
+    static_assert(32 * PLANE + 3 + NW * 2 * WLANES * 4 <= 32 * 577 + 3 + NW * 2 * WLANES * 4, "LDS sized for the largest shape");
 
     const int frame = p.frame0 + blockIdx.z;
     const LevelDesc d = p.lv[tile.level];
@@ -56,6 +60,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
     constexpr int a = K / 2;
     const int t = threadIdx.x;
     const float *feat = featp + ((size_t)frame * p.cell_per_frame + d.cell_off) * 32;
+    // wrapped tile: `la` positions in the first segment; its patch occupies LDS columns [0, la + K - 1), the second segment's
+    // the columns from there on
+    const int la = WRAP ? min(W - tile.x0, 64) : 0;
 
     {   // stage: 8 lanes read the 128-byte cell of a position as 4 channels each, NW*8 cells per pass, in
         // batches of UB independent loads; each lane then scatters its 4 channels to their planes
@@ -69,7 +76,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
             for (int u = 0; u < UB; ++u) {
                 const int ci = (it0 + u) * CPP + cell0;
                 const int cy = ci / PW, cx = ci - cy * PW;
-                const int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
+                int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
+                if (WRAP) {
+                    const bool second = cx >= la + K - 1;
+                    gy = 4 * (tile.y0 + (second ? 1 : 0)) + cy - a;
+                    gx = second ? cx - (la + K - 1) - a : tile.x0 + cx - a;
+                }
                 v[u] = border;
                 if (it0 + u < NIT && ci < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W)
                     v[u] = *reinterpret_cast<const v4f *>(feat + ((size_t)gy * W + gx) * 32 + c4 * 4);
@@ -90,8 +102,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
 
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int px = lane & (TW - 1), py = (lane >> (5 - S)) * P;
-    const int x = tile.x0 + px, y = tile.y0 + py;
+    const bool second = WRAP && lane >= la;
+    const int px = WRAP ? lane + (second ? K - 1 : 0) : lane & (TW - 1);                  // LDS column of the lane's window
+    const int py = WRAP ? 0 : (lane >> (WRAP ? 0 : 5 - S)) * P;
+    const int x = WRAP ? (second ? lane - la : tile.x0 + lane) : tile.x0 + px;
+    const int y = WRAP ? 4 * (tile.y0 + (second ? 1 : 0)) : tile.y0 + py;
     const int ngroups = p.Fpad / Q;
     const int g1 = min(g0 + p.groups_per_block, ngroups);
     const size_t HW = (size_t)H * W;
@@ -100,7 +115,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
     // HOG channel 31 is 0 inside the image (1 only in the constant border): a tile whose haloed patch lies inside the level
     // skips that channel (about a third of the tiles; exact mode only -- a fused multiply-add of zeros changes nothing either,
     // but the FMA mode is kept literal)
-    const bool skip31 = !FMA && p.c31_zero && tile.y0 >= a && tile.x0 >= a && tile.y0 + TH + a <= H && tile.x0 + TW + a <= W;
+    const bool skip31 = WRAP ? (!FMA && p.c31_zero && la >= 64 && 4 * tile.y0 >= a && tile.x0 >= a && 4 * tile.y0 + TH + a <= H && tile.x0 + TW + a <= W)
+                             : (!FMA && p.c31_zero && tile.y0 >= a && tile.x0 >= a && tile.y0 + TH + a <= H && tile.x0 + TW + a <= W);
     // wave-private weight slice, 16-byte aligned
     float *wbuf = sm + ((32 * PLANE + 3) & ~3) + wave * (2 * WLANES * 4);
     // lanes past the last 16-byte piece of the 800-byte weight block repeat the last piece (same address, same data): the
@@ -299,13 +315,14 @@ template <int K, bool FMA, int NW>
 __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p, const float *__restrict__ wts, const float *__restrict__ featp,
                                                   float *__restrict__ respp)
 {
-    __shared__ __attribute__((aligned(16))) float sm[32 * 433 + 3 + NW * 2 * ((K * K * kConvQ + 3) / 4) * 4];
+    __shared__ __attribute__((aligned(16))) float sm[32 * 577 + 3 + NW * 2 * ((K * K * kConvQ + 3) / 4) * 4];
     __shared__ int next_g;
     const int b = blockIdx.x;
-    const ConvTile tile = p.shaped[b];
-    if (b < p.nshaped[0]) conv_tile<K, FMA, NW, 0>(p, wts, featp, respp, sm, &next_g, tile);
-    else if (b < p.nshaped[0] + p.nshaped[1]) conv_tile<K, FMA, NW, 1>(p, wts, featp, respp, sm, &next_g, tile);
-    else conv_tile<K, FMA, NW, 2>(p, wts, featp, respp, sm, &next_g, tile);
+    const ConvTile tile = p.shaped4[b];
+    if (b < p.nshaped4[0]) conv_tile<K, FMA, NW, 0>(p, wts, featp, respp, sm, &next_g, tile);
+    else if (b < p.nshaped4[0] + p.nshaped4[1]) conv_tile<K, FMA, NW, 1>(p, wts, featp, respp, sm, &next_g, tile);
+    else if (b < p.nshaped4[0] + p.nshaped4[1] + p.nshaped4[2]) conv_tile<K, FMA, NW, 2>(p, wts, featp, respp, sm, &next_g, tile);
+    else conv_tile<K, FMA, NW, 3>(p, wts, featp, respp, sm, &next_g, tile);
 }
 
 // generic kernel: any filter size, any real type R (the reference's T=double instantiation runs here);
@@ -400,7 +417,7 @@ static void launch_generic(const ConvParams &p, dim3 grid, hipStream_t s)
 template <bool FMA, int NW>
 static void launch_shapes(const ConvParams &p, int gy, int nframes, hipStream_t s)
 {
-    const int nt = p.nshaped[0] + p.nshaped[1] + p.nshaped[2];
+    const int nt = p.nshaped4[0] + p.nshaped4[1] + p.nshaped4[2] + p.nshaped4[3];
     hipLaunchKernelGGL((k_conv<5, FMA, NW>), dim3(nt, gy, nframes), dim3(NW * 64), 0, s, p, static_cast<const float *>(p.wts),
                        static_cast<const float *>(p.feat), static_cast<float *>(p.resp));
 }
