@@ -91,12 +91,14 @@ def test_conv_pdf(det_mod, oracle, mode):
     conv = det_mod.SpatialConvolutionEngine(hd)
     rng = np.random.default_rng(5)
     # ragged levels incl. maps smaller than the filter and one empty level
-    dims = [(37, 45), (8, 33), (3, 2), (1, 1), (0, 5), (12, 70)]
+    # (levels at least 64 cells wide are covered by tiles that wrap from one four-row strip into the next)
+    dims = [(37, 45), (8, 33), (3, 2), (1, 1), (0, 5), (12, 70), (5, 64), (4, 65), (9, 130), (7, 201), (66, 97)]
     feats = [(rng.random((h, w * 32), dtype=np.float32) * 0.4) for h, w in dims]
     for f in feats:
         if f.size:
             f.reshape(f.shape[0], -1, 32)[:, :, 31] = 0.0
     feats[1].reshape(8, 33, 32)[:, :, 31] = 0.3   # a non-zero last channel inside the image
+    feats[8].reshape(9, 130, 32)[:, :, 31] = 0.2
     got = conv.pdf(feats)
     for (h, w), f, g in zip(dims, feats, got):
         assert g.shape == (flat.nfilters, h, w)
