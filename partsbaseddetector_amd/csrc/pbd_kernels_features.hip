@@ -699,10 +699,6 @@ __global__ __launch_bounds__(TBX * TBY) void k_hog_tile(HogParams p)
     const uint8_t *im = p.pyr + ((size_t)frame * p.pix_per_frame + d.img_off) * 3;
     const size_t stride = (size_t)cols * 3;
     const long long npix = (long long)rows * cols;
-#ifdef PBD_HOG_ABL_NOA
-    for (int q = t; q < PWY * LW; q += NT) { s_mag[q] = 1.0f; s_ori[q] = (uint8_t)(q % 18); }
-    if (false)
-#endif
     for (int q = t; q < PWY * NQ; q += NT) {
         const int py = q / NQ, px = (q - py * NQ) * 4;
         const int y = oy + py, x = ox + px;
@@ -772,9 +768,6 @@ __global__ __launch_bounds__(TBX * TBY) void k_hog_tile(HogParams p)
             else if (cx.ip + 1 == bx) { wxs[i] = cx.v0; xoff[i] = (x < cols - 2 ? x : cols - 2) - ox; }
         }
     }
-#ifdef PBD_HOG_ABL_NOB
-    if (s_mag[t] == 123.0f)
-#endif
     for (int y = ylo; y < yhi; ++y) {
         const HogCoordT<float> cy = coord[y];
         float wy;
