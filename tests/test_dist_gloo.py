@@ -114,7 +114,7 @@ def test_candidate_gatherer_world2():
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29655
+    port = _free_port()
     procs = [ctx.Process(target=_gatherer_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
