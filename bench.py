@@ -202,7 +202,7 @@ def main():
         work = {
             "k_conv": {"bytes": (128 * cells + 4 * F * ktaps + 4 * F * cells) * B, "flop": 2.0 * ktaps * F * cells * B},
             "k_dt_rows": {"bytes": (8 + pb) * cells * jobs * B},      # read score 4, write tmp 4 + Ix
-            "k_dt_cols": {"bytes": (8 + 3 * pb) * cells * jobs * B},  # read tmp 4 + Ix, write dt 4 + Iy + Ix
+            "k_dt_cols": {"bytes": (8 + pb) * cells * jobs * B},      # read tmp 4, write dt 4 + Iy (the rows pass writes Ix in place)
             "k_dp_combine": {"bytes": comb * cells * B},        # per child: dt/Ix in, Ix/Iy/Ik out; per parent: score in/out
             "k_hog_hist": {"bytes": (3 * int(np.sum(plan["img_rows"].astype(np.int64) * plan["img_cols"])) + 76 * cells) * B},
         }

@@ -228,7 +228,7 @@ struct pbd_handle {
 
     // workspace
     DevBuf frames, pyr, gmag, gori, hist, norm, feat, resp, acc, Ix, Iy, Ik, rootv, rooti;
-    DevBuf tmp, dt, IxT, IxRaw, IyRaw, stk, cand, count, scales_tmp;
+    DevBuf tmp, dt, IxRaw, IyRaw, stk, cand, count, scales_tmp;
     std::vector<int32_t> cand_host;
 
     // pipelined host entry points (pbd_detect_batch_submit / _wait): two batches may be in flight
@@ -1050,7 +1050,6 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
     HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16) + 32));            // + slack: the combine step reads whole cell groups
-    HIPCHK(h, h->IxT.ensure(std::max<size_t>(per_frame * chunk * pes, 16) + 16));      // + slack: 16-byte chunk reads
     HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16) + 32));
     HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16)));
     HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkPairF64 : kStkPairF32), 16)));
@@ -1066,7 +1065,7 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     dp.resp = h->resp.p; dp.resp_half = h->resp_half ? 1 : 0; dp.acc = h->acc.p;
     dp.Ix = h->Ix.p; dp.Iy = h->Iy.p; dp.Ik = h->Ik.as<uint8_t>(); dp.ptr8 = P.ptr8 ? 1 : 0;
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;
-    dp.IxT = h->IxT.p; dp.IxRaw = h->IxRaw.p; dp.IyRaw = h->IyRaw.p;
+    dp.IxRaw = h->IxRaw.p; dp.IyRaw = h->IyRaw.p;
     dp.stk = h->stk.p; dp.stk_per_jf = P.stk_per_jf;
     dp.stk_row_off = P.d_stk_row_off.d; dp.stk_col_off = P.d_stk_col_off.d;
     dp.biasw = h->d_biasw.d;
@@ -1375,7 +1374,7 @@ void pbd_destroy(pbd_handle *h)
     for (auto e : h->chunk_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (DevBuf *b : {&h->frames, &h->pyr, &h->gmag, &h->gori, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
-                      &h->rooti, &h->tmp, &h->dt, &h->IxT, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
+                      &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();
     for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); }

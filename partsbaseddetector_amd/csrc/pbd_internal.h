@@ -182,7 +182,6 @@ struct DpParams {
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
     long long quad_per_frame;
     int max_mix;                  // largest number of mixtures of any part of the model (<= kMaxMix)
-    void *IxT;                    // rows-pass pointers, transposed [x][y] (uint8 / int16 as Ix)
     void *IxRaw, *IyRaw;          // row-major pointers written by the columns pass
     void *stk;                    // [chunk][JG][stk_per_jf] records of two entries, wave-private, lane-interleaved
     long long stk_per_jf;         // records per (job, frame)

@@ -116,7 +116,6 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 
     constexpr size_t kStep = (size_t)MT * NV * 64;
     constexpr int NSTEP = K * K * 2;
     const size_t HW = (size_t)H * W;
-    float *resp = respp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F;
 
     // The 8 N-tiles are done in two halves of 4 (64 accumulator registers instead of 128): with ~110 registers per
     // lane four waves fit a SIMD, so two or three 5-wave workgroups share a CU and one's matrix work covers the

@@ -276,12 +276,15 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const bool hsrc = RH && !job.from_acc;
     const _Float16 *srch = static_cast<const _Float16 *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F +
                            (size_t)job.plane * HW + (size_t)y * W;
-    // outputs go out TRANSPOSED ([x][y]): lanes are adjacent rows y, so every store instruction writes
-    // whole lines; the columns pass reads its own column back with wide per-lane loads
+    // the transformed values go out TRANSPOSED ([x][y]): lanes are adjacent rows y, so every store instruction writes
+    // whole lines; the columns pass reads its own column back with wide per-lane loads.  The pointers go straight to their
+    // final row-major plane (IxRaw[y][x], what the combine step reads): a lane's chunk of them is contiguous there and, packed
+    // as it already is, leaves as ONE wide store -- the columns pass used to carry them along (a load, 16 extracts and 16 byte
+    // stores per chunk, 8 registers) only to transpose them
     const int Hl = d.rows;
-    const size_t obase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW + (size_t)y;
-    R *tmpT = static_cast<R *>(p.tmp) + obase;
-    PT *ixT = static_cast<PT *>(p.IxT) + obase;
+    const size_t jb = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
+    R *tmpT = static_cast<R *>(p.tmp) + jb + (size_t)y;
+    PT *ixrow = static_cast<PT *>(p.IxRaw) + jb + (size_t)y * W;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
@@ -316,11 +319,21 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     auto store = [&](int q0, const R *out, const int *ptr, const int *) {
         // the element pointers advance by additions (a 64-bit multiply per store is a quarter-rate instruction)
         R *tp = tmpT + (size_t)q0 * Hl;
-        PT *ip = ixT + (size_t)q0 * Hl;
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i) {
-            if (q0 + i < N) { *tp = out[i]; *ip = (PT)dt_get<EPW>(ptr, i); }
-            tp += Hl; ip += Hl;
+            if (q0 + i < N) *tp = out[i];
+            tp += Hl;
+        }
+        if (EPW > 1 && q0 + kDtCH <= N) {
+            typedef unsigned vpw_u __attribute__((ext_vector_type(kDtCH / EPW), aligned(1)));
+            vpw_u w;
+#pragma unroll
+            for (int e = 0; e < kDtCH / EPW; ++e) w[e] = (unsigned)ptr[e];
+            *reinterpret_cast<vpw_u *>(ixrow + q0) = w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < kDtCH; ++i)
+                if (q0 + i < N) ixrow[q0 + i] = (PT)dt_get<EPW>(ptr, i);
         }
     };
     auto noaux = [](int, int *) {};
@@ -361,10 +374,8 @@ void k_dt_cols(DpParams p)
     const DtJob job = p.jobs[j];
     const size_t jbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
     const R *tmpT = static_cast<const R *>(p.tmp) + jbase + (size_t)x * H;     // this lane's column, contiguous
-    const PT *ixT = static_cast<const PT *>(p.IxT) + jbase + (size_t)x * H;
     R *dt = static_cast<R *>(p.dt) + jbase + x;
     PT *iyr = static_cast<PT *>(p.IyRaw) + jbase + x;
-    PT *ixr = static_cast<PT *>(p.IxRaw) + jbase + x;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
@@ -382,42 +393,20 @@ void k_dt_cols(DpParams p)
             for (int i = 0; i < kDtCHC; ++i) buf[i] = (q0 + i < H) ? tmpT[q0 + i] : (R)0;
         }
     };
-    auto aux = [&](int q0, int *buf) {      // the rows pass's pointers of this column
-        if (q0 + kDtCHC <= H) {
-            if constexpr (sizeof(PT) == 1) {
-                const vchw_u a0 = *reinterpret_cast<const vchw_u *>(ixT + q0);   // one load per chunk of uint8 positions, kept packed
-#pragma unroll
-                for (int e = 0; e < kDtCHC / 4; ++e) buf[e] = (int)a0[e];
-            } else {
-                typedef unsigned v4w_u __attribute__((ext_vector_type(4), aligned(2)));
-#pragma unroll
-                for (int v = 0; v < kDtCHC / 8; ++v) {      // 8 int16 positions = 4 words, kept packed
-                    const v4w_u a0 = *reinterpret_cast<const v4w_u *>(ixT + q0 + 8 * v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) buf[4 * v + e] = (int)a0[e];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < kDtCHC / EPW; ++i) buf[i] = 0;
-#pragma unroll
-            for (int i = 0; i < kDtCHC; ++i) dt_put<EPW>(buf, i, (q0 + i < H) ? (int)ixT[q0 + i] : 0);
-        }
-    };
-    auto store = [&](int q0, const R *out, const int *ptr, const int *ix) {
+    auto noaux = [](int, int *) {};
+    auto store = [&](int q0, const R *out, const int *ptr, const int *) {
         R *dp = dt + (size_t)q0 * W;
-        PT *yp = iyr + (size_t)q0 * W, *xp = ixr + (size_t)q0 * W;
+        PT *yp = iyr + (size_t)q0 * W;
 #pragma unroll
         for (int i = 0; i < kDtCHC; ++i) {
             if (q0 + i < H) {
                 *dp = out[i];
                 *yp = (PT)dt_get<EPW>(ptr, i);
-                *xp = (PT)dt_get<EPW>(ix, i);
             }
-            dp += W; yp += W; xp += W;
+            dp += W; yp += W;
         }
     };
-    dt_stream<R, true, BZ, kDtCHC, EPW>(H, job.ay, job.by, job.osy, ring, load, store, aux);
+    dt_stream<R, false, BZ, kDtCHC, EPW>(H, job.ay, job.by, job.osy, ring, load, store, noaux);
 }
 
 void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
