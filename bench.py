@@ -196,14 +196,14 @@ def main():
                 gpar = p0 + int(flat.parentid[gp])
                 K, L = nmix(gp), nmix(gpar)
                 jobs += K                                   # (part, mixture) distance transforms per level
-                comb += K * (4 + pb) + L * (pb + 2 * pb + 1)  # per child: dt + Ix in, Iy gather, Ix/Iy/Ik out
+                comb += K * 4 + L * 1                       # per child: dt in, Ik out (Ix / Iy are composed lazily from the transform's planes)
                 parents.add(gpar)
         comb += sum(8 * nmix(g) for g in parents)           # per parent: response in, accumulated score out
         work = {
             "k_conv": {"bytes": (128 * cells + 4 * F * ktaps + 4 * F * cells) * B, "flop": 2.0 * ktaps * F * cells * B},
             "k_dt_rows": {"bytes": (8 + pb) * cells * jobs * B},      # read score 4, write tmp 4 + Ix
             "k_dt_cols": {"bytes": (8 + pb) * cells * jobs * B},      # read tmp 4, write dt 4 + Iy (the rows pass writes Ix in place)
-            "k_dp_combine": {"bytes": comb * cells * B},        # per child: dt/Ix in, Ix/Iy/Ik out; per parent: score in/out
+            "k_dp_combine": {"bytes": comb * cells * B},        # per child: dt in, Ik out; per parent: score in/out
             "k_hog_hist": {"bytes": (3 * int(np.sum(plan["img_rows"].astype(np.int64) * plan["img_cols"])) + 76 * cells) * B},
         }
         stage_ms = {k: round(ms / args.steps, 4) for k, (ms, n) in prof.items() if n}

@@ -227,7 +227,8 @@ struct pbd_handle {
     bool feat_c31_zero = false;      // h->feat was written by the HOG kernels (channel 31 = 0), not uploaded by the caller
 
     // workspace
-    DevBuf frames, pyr, gmag, gori, hist, norm, feat, resp, acc, Ix, Iy, Ik, rootv, rooti;
+    DevBuf frames, pyr, gmag, gori, hist, norm, feat, resp, acc, Ik, rootv, rooti;
+    int totmix = 0;                  // (part, mixture) pairs of the model = planes of IxRaw / IyRaw per cell block
     DevBuf tmp, dt, IxRaw, IyRaw, stk, cand, count, scales_tmp;
     std::vector<int32_t> cand_host;
 
@@ -810,10 +811,12 @@ int build_model(pbd_handle *h, const pbd_model *m)
     h->groups.clear();
     h->JGmax = 0;
     h->NM = totmix;
+    h->totmix = totmix;
     auto dt_job = [&](int gm, bool from_acc, int plane) {
         DtJob j{};
         j.from_acc = from_acc ? 1 : 0;
         j.plane = plane;
+        j.gm = gm;
         const int d = h->defid[gm];
         const float *w = &h->defw[(size_t)d * 4];
         j.ax = (double)(-w[0]); j.bx = (double)(-w[1]); j.ay = (double)(-w[2]); j.by = (double)(-w[3]);
@@ -925,6 +928,7 @@ int build_model(pbd_handle *h, const pbd_model *m)
             PartWalk w{};
             w.parent = h->parentid[p0 + p];
             w.slot = h->ptr_slot[p0 + p];
+            w.mix0 = h->mix_offset[p0 + p];
             const int K = h->mix_offset[p0 + p + 1] - h->mix_offset[p0 + p];
             for (int mm = 0; mm < K; ++mm) w.ksize[mm] = m->filter_ksize[h->filterid[h->mix_offset[p0 + p] + mm]];
             h->walk.push_back(w);
@@ -1041,8 +1045,6 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     const int NSa = std::max(h->NS, 1);
     HIPCHK(h, h->acc.ensure(std::max<size_t>((size_t)nframes * cpf * std::max(h->NM, 1) * h->rs, 16)));
     const size_t pes = P.ptr8 ? 1 : 2;        // bytes per position
-    HIPCHK(h, h->Ix.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * pes, 16)));
-    HIPCHK(h, h->Iy.ensure(std::max<size_t>((size_t)nframes * cpf * NSa * pes, 16)));
     HIPCHK(h, h->Ik.ensure(std::max<size_t>((size_t)nframes * cpf * NSa, 16)));
     HIPCHK(h, h->rootv.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * h->rs, 16)));
     HIPCHK(h, h->rooti.ensure(std::max<size_t>((size_t)nframes * cpf * h->NC * sizeof(int), 16)));
@@ -1050,8 +1052,9 @@ int alloc_dp(pbd_handle *h, Plan &P, int nframes, int chunk)
     const size_t stk_per_frame = (size_t)P.stk_per_jf * std::max(h->JGmax, 1);
     HIPCHK(h, h->tmp.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16)));
     HIPCHK(h, h->dt.ensure(std::max<size_t>(per_frame * chunk * h->rs, 16) + 32));            // + slack: the combine step reads whole cell groups
-    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16) + 32));
-    HIPCHK(h, h->IyRaw.ensure(std::max<size_t>(per_frame * chunk * pes, 16)));
+    // the transform's pointer planes are kept for the whole batch (one plane per (part, mixture)): the walk composes Ix / Iy from them
+    HIPCHK(h, h->IxRaw.ensure(std::max<size_t>((size_t)nframes * cpf * std::max(h->totmix, 1) * pes, 16) + 32));
+    HIPCHK(h, h->IyRaw.ensure(std::max<size_t>((size_t)nframes * cpf * std::max(h->totmix, 1) * pes, 16) + 32));
     HIPCHK(h, h->stk.ensure(std::max<size_t>(stk_per_frame * chunk * (h->f64 ? kStkPairF64 : kStkPairF32), 16)));
     return PBD_OK;
 }
@@ -1063,7 +1066,7 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     dp.lv = P.d_lv.d; dp.nlevels = P.nlevels; dp.F = h->F; dp.NS = h->NS; dp.NC = h->NC; dp.NM = h->NM;
     dp.cell_per_frame = P.cell_per_frame; dp.quad_per_frame = P.quad_per_frame; dp.max_mix = h->max_mix;
     dp.resp = h->resp.p; dp.resp_half = h->resp_half ? 1 : 0; dp.acc = h->acc.p;
-    dp.Ix = h->Ix.p; dp.Iy = h->Iy.p; dp.Ik = h->Ik.as<uint8_t>(); dp.ptr8 = P.ptr8 ? 1 : 0;
+    dp.Ik = h->Ik.as<uint8_t>(); dp.NJ = h->totmix; dp.ptr8 = P.ptr8 ? 1 : 0;
     dp.tmp = h->tmp.p; dp.dt = h->dt.p;
     dp.IxRaw = h->IxRaw.p; dp.IyRaw = h->IyRaw.p;
     dp.stk = h->stk.p; dp.stk_per_jf = P.stk_per_jf;
@@ -1127,7 +1130,7 @@ ArgminParams argmin_params(pbd_handle *h, Plan &P, int nframes, const float *d_s
     ap.lv = P.d_lv.d; ap.nlevels = P.nlevels; ap.NS = h->NS; ap.NC = h->NC; ap.nframes = nframes;
     ap.cell_per_frame = P.cell_per_frame;
     ap.rootv = h->rootv.p; ap.rooti = h->rooti.as<int>();
-    ap.Ix = h->Ix.p; ap.Iy = h->Iy.p; ap.Ik = h->Ik.as<uint8_t>(); ap.ptr8 = P.ptr8 ? 1 : 0;
+    ap.IxRaw = h->IxRaw.p; ap.IyRaw = h->IyRaw.p; ap.NJ = h->totmix; ap.Ik = h->Ik.as<uint8_t>(); ap.ptr8 = P.ptr8 ? 1 : 0;
     ap.thresh = h->thresh; ap.scales = d_scales;
     ap.walk = h->d_walk.d; ap.walk_off = h->d_walk_off.d;
     ap.max_parts = h->max_parts; ap.stride = 8 + 4 * h->max_parts; ap.capacity = std::max(h->cfg.max_candidates, 1);
@@ -1373,7 +1376,7 @@ void pbd_destroy(pbd_handle *h)
     if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
     for (auto e : h->chunk_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    for (DevBuf *b : {&h->frames, &h->pyr, &h->gmag, &h->gori, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ix, &h->Iy, &h->Ik, &h->rootv,
+    for (DevBuf *b : {&h->frames, &h->pyr, &h->gmag, &h->gori, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ik, &h->rootv,
                       &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
                       &h->scales_tmp})
         b->release();
@@ -1570,32 +1573,57 @@ int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, con
         h->cur = P; h->cur_frames = 1; h->have_resp = true; h->have_dp = false;
         if ((rc = run_dp(h, *P, 1)) != PBD_OK) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        std::vector<int16_t> t16;
         std::vector<uint8_t> t8;
         for (int l = 0; l < nlevels; ++l) {
             const size_t hw = (size_t)rows[l] * cols[l];
             if (!hw) continue;
             const size_t n = hw * h->NS, off = (size_t)P->lv[l].cell_off * h->NS;
             if (n) {
-                t16.resize(n); t8.resize(n);
-                // positions are uint8 on the device when no level side exceeds 256 (Plan::ptr8), int16 otherwise
-                auto fetch_pos = [&](const DevBuf &src, int *dst) -> hipError_t {
-                    if (P->ptr8) {
-                        hipError_t e = hipMemcpy(t8.data(), src.as<uint8_t>() + off, n, hipMemcpyDeviceToHost);
+                t8.resize(n);
+                // the device keeps the winning mixture per slot (Ik) and the transform's own pointer planes per (part, mixture);
+                // the reference's Ix / Iy of a slot are composed here: Ix = IxRaw[k][y][x], Iy = IyRaw[k][y][Ix], k = Ik
+                HIPCHK(h, hipMemcpy(t8.data(), h->Ik.as<uint8_t>() + off, n, hipMemcpyDeviceToHost));
+                std::vector<uint8_t> ik(t8.begin(), t8.begin() + n);
+                if (Ik && Ik[l]) for (size_t i = 0; i < n; ++i) Ik[l][i] = ik[i];
+                if ((Ix && Ix[l]) || (Iy && Iy[l])) {
+                    const size_t nj = hw * h->totmix, joff = (size_t)P->lv[l].cell_off * h->totmix;
+                    std::vector<int> px(nj), py(nj);
+                    auto fetch_planes = [&](const DevBuf &src, std::vector<int> &dst) -> hipError_t {
+                        if (P->ptr8) {
+                            std::vector<uint8_t> b(nj);
+                            hipError_t e = hipMemcpy(b.data(), src.as<uint8_t>() + joff, nj, hipMemcpyDeviceToHost);
+                            if (e != hipSuccess) return e;
+                            for (size_t i = 0; i < nj; ++i) dst[i] = b[i];
+                            return hipSuccess;
+                        }
+                        std::vector<int16_t> b(nj);
+                        hipError_t e = hipMemcpy(b.data(), src.as<int16_t>() + joff, nj * 2, hipMemcpyDeviceToHost);
                         if (e != hipSuccess) return e;
-                        for (size_t i = 0; i < n; ++i) dst[i] = t8[i];
+                        for (size_t i = 0; i < nj; ++i) dst[i] = b[i];
                         return hipSuccess;
+                    };
+                    HIPCHK(h, fetch_planes(h->IxRaw, px));
+                    HIPCHK(h, fetch_planes(h->IyRaw, py));
+                    const int Wl = cols[l];
+                    const int totparts = (int)h->parentid.size();
+                    for (int gp = 0; gp < totparts; ++gp) {
+                        bool root = false;
+                        for (int c = 0; c < h->NC; ++c) root = root || gp == h->part_offset[c];
+                        if (root) continue;
+                        int c = 0;
+                        while (c + 1 < h->NC && h->part_offset[c + 1] <= gp) ++c;
+                        const int gpar = h->part_offset[c] + h->parentid[gp];
+                        const int L = h->mix_offset[gpar + 1] - h->mix_offset[gpar];
+                        for (int pm = 0; pm < L; ++pm) {
+                            const size_t so = (size_t)(h->ptr_slot[gp] + pm) * hw;
+                            for (size_t cell = 0; cell < hw; ++cell) {
+                                const size_t plane = (size_t)(h->mix_offset[gp] + ik[so + cell]) * hw;
+                                const int x = px[plane + cell];
+                                if (Ix && Ix[l]) Ix[l][so + cell] = x;
+                                if (Iy && Iy[l]) Iy[l][so + cell] = py[plane + (cell / Wl) * Wl + x];
+                            }
+                        }
                     }
-                    hipError_t e = hipMemcpy(t16.data(), src.as<int16_t>() + off, n * 2, hipMemcpyDeviceToHost);
-                    if (e != hipSuccess) return e;
-                    for (size_t i = 0; i < n; ++i) dst[i] = t16[i];
-                    return hipSuccess;
-                };
-                if (Ix && Ix[l]) HIPCHK(h, fetch_pos(h->Ix, Ix[l]));
-                if (Iy && Iy[l]) HIPCHK(h, fetch_pos(h->Iy, Iy[l]));
-                if (Ik && Ik[l]) {
-                    HIPCHK(h, hipMemcpy(t8.data(), h->Ik.as<uint8_t>() + off, n, hipMemcpyDeviceToHost));
-                    for (size_t i = 0; i < n; ++i) Ik[l][i] = t8[i];
                 }
             }
             const size_t roff = (size_t)P->lv[l].cell_off * h->NC;

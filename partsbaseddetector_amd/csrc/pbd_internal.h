@@ -52,6 +52,7 @@ inline int hog_tile_rows(int sbin) { return sbin <= 4 ? 16 : 8; }
 struct DtJob {
     int plane;                // filter id (from_acc == 0) or global mixture index (from_acc == 1)
     int from_acc;
+    int gm;                   // global (part, mixture) index: the job's plane in the persistent pointer buffers IxRaw / IyRaw
     int osx, osy;             // anchor
     double ax, bx, ay, by;    // Quadratic(-w0,-w1), Quadratic(-w2,-w3)  (src/DynamicProgram.cpp:125-127)
 };
@@ -99,6 +100,7 @@ struct SeqCombineJob {
 struct PartWalk {             // argmin tree walk, one per part of a component
     int parent;               // local parent index
     int slot;                 // ptr_slot
+    int mix0;                 // global (part, mixture) index of the part's mixture 0
     int ksize[8];             // filter size per mixture (xsize == ysize == rows, include/Parts.hpp:185-187)
 };
 
@@ -174,15 +176,20 @@ struct DpParams {
     int bz_x, bz_y;               // every job of the launch has a linear coefficient of exactly -0.0 (and a != 0) along x / y
     int resp_half;
     void *acc;                    // R [frames][cell_per_frame*NM] accumulated scores of non-leaf parts
-    void *Ix, *Iy;                // [frames][cell_per_frame*NS] back-pointers: uint8 when ptr8 (no map side exceeds 256), else int16
-    uint8_t *Ik;
+    uint8_t *Ik;                  // [frames][cell_per_frame*NS] winning child mixture per (part, parent mixture) slot
+    int NJ;                       // planes per cell block of IxRaw / IyRaw (= (part, mixture) pairs of the model)
     int ptr8;
     // group scratch, indexed by chunk-local frame
     int JG;                       // jobs in this group
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
     long long quad_per_frame;
     int max_mix;                  // largest number of mixtures of any part of the model (<= kMaxMix)
-    void *IxRaw, *IyRaw;          // row-major pointers written by the columns pass
+    // the transform's own pointers, row-major, KEPT for the whole batch ([frames][cell_per_frame*NJ], plane = DtJob::gm; uint8
+    // when ptr8, else int16): IxRaw[y][x] from the rows pass, IyRaw[y][x] from the columns pass.  The reference's Ix / Iy of a
+    // (part, parent mixture) slot are Ix = IxRaw[k][y][x], Iy = IyRaw[k][y][Ix] with k = Ik (include/DistanceTransform.hpp:233-244,
+    // src/DynamicProgram.cpp:146-152); only the candidates' walks and pbd_dp_min's read-back ever need them, so they are
+    // composed there instead of for every cell
+    void *IxRaw, *IyRaw;
     void *stk;                    // [chunk][JG][stk_per_jf] records of two entries, wave-private, lane-interleaved
     long long stk_per_jf;         // records per (job, frame)
     const long long *stk_row_off; // per rows-pass wave (64 flat rows): first entry
@@ -204,7 +211,8 @@ struct ArgminParams {
     int nlevels, NS, NC, nframes;
     long long cell_per_frame;
     const void *rootv; const int *rooti;   // rootv: R
-    const void *Ix, *Iy; const uint8_t *Ik;
+    const void *IxRaw, *IyRaw; const uint8_t *Ik;     // see DpParams
+    int NJ;
     int ptr8;
     float thresh;
     const float *scales;          // [nlevels]

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const int Hl = d.rows;
     const size_t jb = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
     R *tmpT = static_cast<R *>(p.tmp) + jb + (size_t)y;
-    PT *ixrow = static_cast<PT *>(p.IxRaw) + jb + (size_t)y * W;
+    PT *ixrow = static_cast<PT *>(p.IxRaw) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + (size_t)y * W;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
@@ -375,7 +375,7 @@ void k_dt_cols(DpParams p)
     const size_t jbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
     const R *tmpT = static_cast<const R *>(p.tmp) + jbase + (size_t)x * H;     // this lane's column, contiguous
     R *dt = static_cast<R *>(p.dt) + jbase + x;
-    PT *iyr = static_cast<PT *>(p.IyRaw) + jbase + x;
+    PT *iyr = static_cast<PT *>(p.IyRaw) + ((size_t)(p.frame0 + fl) * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + x;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
@@ -493,9 +493,6 @@ void k_dp_combine(DpParams p)
     const int local = (int)(qidx - d.quad_off) * 4 + (int)(gidx % SUB) * kCpt;
     if (local >= HWi) return;
     const int n = min(kCpt, HWi - local);
-    int rowbase[kCpt];       // y * W of each cell
-#pragma unroll
-    for (int e = 0; e < kCpt; ++e) rowbase[e] = (min(local + e, HWi - 1) / W) * W;
     const R *resp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + local;
     const R *dtp = static_cast<const R *>(p.dt);
     const size_t gbase0 = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG;
@@ -539,27 +536,24 @@ void k_dp_combine(DpParams p)
             for (int pm = 0; pm < MAXM; ++pm)
                 bw[mm][pm] = (mm < cd.nmix && pm < cj.npar) ? biasw[cd.bias_off[mm] + pm] : 0.0f;
         R dtv[MAXM][kCpt];
-        PT ixv[MAXM][kCpt];
 #pragma unroll
         for (int mm = 0; mm < MAXM; ++mm) {
 #pragma unroll
             // a mixture the child does not have scores -inf: it can never win the strict `>` below, so the selection loop
             // needs no `mm < nmix` test (a uniform branch per candidate, i.e. 144 basic blocks per child with their copies)
-            for (int e = 0; e < kCpt; ++e) { dtv[mm][e] = -RealLimits<R>::inf(); ixv[mm][e] = 0; }
-            if (mm < cd.nmix) {
-                load_cells_wide<R, kCpt>(dtp + gbase + (size_t)mm * HW + local, dtv[mm]);
-                load_cells_wide<PT, kCpt>(static_cast<const PT *>(p.IxRaw) + gbase + (size_t)mm * HW + local, ixv[mm]);
-            }
+            for (int e = 0; e < kCpt; ++e) dtv[mm][e] = -RealLimits<R>::inf();
+            if (mm < cd.nmix) load_cells_wide<R, kCpt>(dtp + gbase + (size_t)mm * HW + local, dtv[mm]);
         }
 #pragma unroll
         for (int pm = 0; pm < MAXM; ++pm) {
             if (pm < cj.npar) {
-                PT oix[kCpt], oiy[kCpt];
+                // only the winning child mixture is recorded (Ik): the positions it points to stay in the transform's own planes
+                // and are composed where they are needed (k_argmin_walk, pbd_dp_min's read-back)
                 uint8_t oik[kCpt];
                 R best[kCpt];
-                int bi[kCpt], ix[kCpt];
+                int bi[kCpt];
 #pragma unroll
-                for (int e = 0; e < kCpt; ++e) { bi[e] = 0; ix[e] = ixv[0][e]; }
+                for (int e = 0; e < kCpt; ++e) bi[e] = 0;
                 if (cd.nmix == 1) {     // K == 1 copies (Math::reduceMax)
 #pragma unroll
                     for (int e = 0; e < kCpt; ++e) best[e] = dtv[0][e] + (R)bw[0][pm];
@@ -573,21 +567,15 @@ void k_dp_combine(DpParams p)
                             const bool t = wv > best[e];
                             best[e] = t ? wv : best[e];
                             bi[e] = t ? mm : bi[e];
-                            ix[e] = t ? (int)ixv[mm][e] : ix[e];
                         }
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < kCpt; ++e) {
-                    // unconditional: cells past the end of the level (e >= n, never stored; their inputs are whatever follows the
-                    // level in the buffers) gather from column 0 of the last valid row
-                    const int iy = static_cast<const PT *>(p.IyRaw)[gbase + (size_t)bi[e] * HW + rowbase[e] + (e < n ? ix[e] : 0)];
-                    oix[e] = (PT)ix[e]; oiy[e] = (PT)iy; oik[e] = (uint8_t)bi[e];
+                    oik[e] = (uint8_t)bi[e];
                     accv[pm][e] = accv[pm][e] + best[e];
                 }
                 const size_t o = pbase + (size_t)(cd.slot + pm) * HW;
-                store_cells<PT, kCpt>(static_cast<PT *>(p.Ix) + o, n, oix);
-                store_cells<PT, kCpt>(static_cast<PT *>(p.Iy) + o, n, oiy);
                 store_cells<uint8_t, kCpt>(p.Ik + o, n, oik);
             }
         }
@@ -638,18 +626,13 @@ __global__ __launch_bounds__(256) void k_dp_combine_seq(DpParams p)
     const int W = d.cols;
     const int local = (int)(idx - d.cell_off);
     const size_t HW = (size_t)d.rows * W;
-    const int rowbase = (local / W) * W;
     const size_t gbase = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)sj.job_begin * HW;
     const size_t pbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS + local;
     const R *respp = static_cast<const R *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + local;
     R *accp = static_cast<R *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM + local;
     const R *dtp = static_cast<const R *>(p.dt) + gbase + local;
     R dtv[kMaxMix];
-    int ixv[kMaxMix];
-    for (int mm = 0; mm < sj.nmix; ++mm) {
-        dtv[mm] = dtp[(size_t)mm * HW];
-        ixv[mm] = static_cast<const PT *>(p.IxRaw)[gbase + (size_t)mm * HW + local];
-    }
+    for (int mm = 0; mm < sj.nmix; ++mm) dtv[mm] = dtp[(size_t)mm * HW];
     for (int pm = 0; pm < sj.npar; ++pm) {
         R best;
         int bi = 0;
@@ -662,10 +645,8 @@ __global__ __launch_bounds__(256) void k_dp_combine_seq(DpParams p)
                 if (wv > best) { bi = mm; best = wv; }
             }
         }
-        const int ix = ixv[bi];
-        const int iy = static_cast<const PT *>(p.IyRaw)[gbase + (size_t)bi * HW + rowbase + ix];
         const size_t o = pbase + (size_t)(sj.slot + pm) * HW;
-        static_cast<PT *>(p.Ix)[o] = (PT)ix; static_cast<PT *>(p.Iy)[o] = (PT)iy; p.Ik[o] = (uint8_t)bi;
+        p.Ik[o] = (uint8_t)bi;
         R *t = accp + (size_t)sj.target[pm] * HW;
         const R base = !sj.init[pm] ? *t
                        : (sizeof(R) == 4 && p.resp_half)
@@ -789,6 +770,7 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
     const PartWalk *walk = p.walk + p.walk_off[c];
     const int nparts = p.walk_off[c + 1] - p.walk_off[c];
     const size_t pbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS;
+    const size_t jbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NJ;
     int32_t *rects = rec + 8;
     // xv/yv/mv of already visited parts are kept in the record itself: x,y in the rect slots
     // (overwritten by the final rect once all children are done is not possible in one pass), so use
@@ -801,8 +783,11 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
         } else {
             const PartWalk w = walk[pidx];
             const int px = xv[w.parent], py = yv[w.parent], pm = mv[w.parent];
-            const size_t o = pbase + (size_t)(w.slot + pm) * HW + (size_t)py * W + px;
-            x = static_cast<const PT *>(p.Ix)[o]; y = static_cast<const PT *>(p.Iy)[o]; m = p.Ik[o];
+            // Ix = IxRaw[k][py][px], Iy = IyRaw[k][py][Ix] with k = the winning mixture (the reference's composition)
+            m = p.Ik[pbase + (size_t)(w.slot + pm) * HW + (size_t)py * W + px];
+            const size_t jo = jbase + (size_t)(w.mix0 + m) * HW + (size_t)py * W;
+            x = static_cast<const PT *>(p.IxRaw)[jo + px];
+            y = static_cast<const PT *>(p.IyRaw)[jo + x];
         }
         xv[pidx] = x; yv[pidx] = y; mv[pidx] = m;
         const int ks = walk[pidx].ksize[m];
