@@ -427,8 +427,10 @@ void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
 // ---- combine: thread = 4 consecutive cells of one level, one PARENT part (block.y) ---------------------
 // For every parent mixture m: acc = response(parent, m); then for each child in descending index order
 //   weighted[mm] = score_dt[child][mm] + bias(mm)[m]; reduceMax (strict >, first wins, start -inf; K==1 copies);
-//   Ix/Iy picked from the winning mixture with the reference's composition Iy[y][x] = IyRaw[y][Ix[y][x]]
-//   (include/DistanceTransform.hpp:233-244); acc += max   (src/DynamicProgram.cpp:134-156).
+//   the winning mixture is recorded as Ik (reducePickIndex); acc += max   (src/DynamicProgram.cpp:134-156).
+//   The reference also picks Ix / Iy of the winner here for every cell (with the composition Iy[y][x] = IyRaw[y][Ix[y][x]],
+//   include/DistanceTransform.hpp:233-244); this path leaves them in the transform's own planes and composes them for the
+//   candidates only (k_argmin_walk) and on read-back (pbd_dp_min).
 // The accumulated plane is the input of the parent's own distance transform in the next group.
 // Four cells per thread: every plane is read and written with 16 / 8 / 4-byte accesses per lane.
 template <typename T, int N> struct CellVec;
@@ -610,8 +612,8 @@ void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hip
 }
 
 // ---- combine, sequential schedule: thread = one cell, block.y = one (component, part) of the step -------------
-// For every parent mixture pm, in order: weighted[mm] = score_dt[mm] + bias(mm)[pm]; reduceMax; pointer pick with the
-// Iy composition; then `parent.score[pm] += max` IN PLACE on the accumulator keyed by the parent mixture's filter id,
+// For every parent mixture pm, in order: weighted[mm] = score_dt[mm] + bias(mm)[pm]; reduceMax; winning mixture -> Ik;
+// then `parent.score[pm] += max` IN PLACE on the accumulator keyed by the parent mixture's filter id,
 // which starts as a copy of the raw response the first time it is touched (src/DynamicProgram.cpp:134-156).
 template <typename R, typename PT>
 __global__ __launch_bounds__(256) void k_dp_combine_seq(DpParams p)
