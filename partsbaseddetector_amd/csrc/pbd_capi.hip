@@ -1618,7 +1618,7 @@ int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, con
                             const size_t so = (size_t)(h->ptr_slot[gp] + pm) * hw;
                             for (size_t cell = 0; cell < hw; ++cell) {
                                 const size_t plane = (size_t)(h->mix_offset[gp] + ik[so + cell]) * hw;
-                                const int x = px[plane + cell];
+                                const int x = px[plane + (cell % Wl) * (size_t)rows[l] + cell / Wl];      // IxRaw is kept transposed
                                 if (Ix && Ix[l]) Ix[l][so + cell] = x;
                                 if (Iy && Iy[l]) Iy[l][so + cell] = py[plane + (cell / Wl) * Wl + x];
                             }

@@ -185,7 +185,7 @@ struct DpParams {
     long long quad_per_frame;
     int max_mix;                  // largest number of mixtures of any part of the model (<= kMaxMix)
     // the transform's own pointers, row-major, KEPT for the whole batch ([frames][cell_per_frame*NJ], plane = DtJob::gm; uint8
-    // when ptr8, else int16): IxRaw[y][x] from the rows pass, IyRaw[y][x] from the columns pass.  The reference's Ix / Iy of a
+    // when ptr8, else int16): IxRaw from the rows pass (stored TRANSPOSED, [x][y], as that pass writes it), IyRaw[y][x] from the columns pass.  The reference's Ix / Iy of a
     // (part, parent mixture) slot are Ix = IxRaw[k][y][x], Iy = IyRaw[k][y][Ix] with k = Ik (include/DistanceTransform.hpp:233-244,
     // src/DynamicProgram.cpp:146-152); only the candidates' walks and pbd_dp_min's read-back ever need them, so they are
     // composed there instead of for every cell

@@ -276,15 +276,15 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const bool hsrc = RH && !job.from_acc;
     const _Float16 *srch = static_cast<const _Float16 *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F +
                            (size_t)job.plane * HW + (size_t)y * W;
-    // the transformed values go out TRANSPOSED ([x][y]): lanes are adjacent rows y, so every store instruction writes
-    // whole lines; the columns pass reads its own column back with wide per-lane loads.  The pointers go straight to their
-    // final row-major plane (IxRaw[y][x], what the combine step reads): a lane's chunk of them is contiguous there and, packed
-    // as it already is, leaves as ONE wide store -- the columns pass used to carry them along (a load, 16 extracts and 16 byte
-    // stores per chunk, 8 registers) only to transpose them
+    // both outputs go out TRANSPOSED ([x][y]): lanes are adjacent rows y, so every store instruction writes whole lines.  The
+    // columns pass reads its column of values back with wide per-lane loads; the pointers go straight to their persistent plane
+    // (IxRaw, kept transposed: only the candidates' walk and pbd_dp_min's read-back ever index it) -- the columns pass used to
+    // carry them along (a load, 16 extracts and 16 byte stores per chunk, 8 registers) only to transpose them for the combine
+    // step, which no longer reads them
     const int Hl = d.rows;
     const size_t jb = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
     R *tmpT = static_cast<R *>(p.tmp) + jb + (size_t)y;
-    PT *ixrow = static_cast<PT *>(p.IxRaw) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + (size_t)y * W;
+    PT *ixT = static_cast<PT *>(p.IxRaw) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + (size_t)y;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
@@ -319,21 +319,11 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     auto store = [&](int q0, const R *out, const int *ptr, const int *) {
         // the element pointers advance by additions (a 64-bit multiply per store is a quarter-rate instruction)
         R *tp = tmpT + (size_t)q0 * Hl;
+        PT *ip = ixT + (size_t)q0 * Hl;
 #pragma unroll
         for (int i = 0; i < kDtCH; ++i) {
-            if (q0 + i < N) *tp = out[i];
-            tp += Hl;
-        }
-        if (EPW > 1 && q0 + kDtCH <= N) {
-            typedef unsigned vpw_u __attribute__((ext_vector_type(kDtCH / EPW), aligned(1)));
-            vpw_u w;
-#pragma unroll
-            for (int e = 0; e < kDtCH / EPW; ++e) w[e] = (unsigned)ptr[e];
-            *reinterpret_cast<vpw_u *>(ixrow + q0) = w;
-        } else {
-#pragma unroll
-            for (int i = 0; i < kDtCH; ++i)
-                if (q0 + i < N) ixrow[q0 + i] = (PT)dt_get<EPW>(ptr, i);
+            if (q0 + i < N) { *tp = out[i]; *ip = (PT)dt_get<EPW>(ptr, i); }
+            tp += Hl; ip += Hl;
         }
     };
     auto noaux = [](int, int *) {};
@@ -787,9 +777,9 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
             const int px = xv[w.parent], py = yv[w.parent], pm = mv[w.parent];
             // Ix = IxRaw[k][py][px], Iy = IyRaw[k][py][Ix] with k = the winning mixture (the reference's composition)
             m = p.Ik[pbase + (size_t)(w.slot + pm) * HW + (size_t)py * W + px];
-            const size_t jo = jbase + (size_t)(w.mix0 + m) * HW + (size_t)py * W;
-            x = static_cast<const PT *>(p.IxRaw)[jo + px];
-            y = static_cast<const PT *>(p.IyRaw)[jo + x];
+            const size_t jo = jbase + (size_t)(w.mix0 + m) * HW;
+            x = static_cast<const PT *>(p.IxRaw)[jo + (size_t)px * d.rows + py];      // IxRaw is kept transposed ([x][y])
+            y = static_cast<const PT *>(p.IyRaw)[jo + (size_t)py * W + x];
         }
         xv[pidx] = x; yv[pidx] = y; mv[pidx] = m;
         const int ks = walk[pidx].ksize[m];
