@@ -27,7 +27,7 @@ static int run(FileStorageModel &model, const Image &im, bool staged, float nms,
         std::vector<MatT<T> > pyramid;
         features.pyramid(im, pyramid);
         std::vector<std::vector<MatT<T> > > pdf, rootv;
-        std::vector<std::vector<MatT<int> > > rooti;
+        std::vector<std::vector<MatT<int32_t> > > rooti;
         conv.pdf(pyramid, pdf);
         dp.min(pdf, rootv, rooti, model.ncomponents());
         dp.argmin(features.scales(), candidates);
@@ -63,7 +63,7 @@ static int dump_model(const FileStorageModel &m)
     std::printf("biasw");
     for (size_t i = 0; i < m.biasw_.size(); ++i) std::printf(" %.9g", (double)m.biasw_[i]);
     std::printf("\nanchors");
-    for (size_t i = 0; i < m.anchors_.size(); ++i) std::printf(" %d,%d", m.anchors_[i].first, m.anchors_[i].second);
+    for (size_t i = 0; i < m.anchors_.size(); ++i) std::printf(" %d,%d", m.anchors_[i].x, m.anchors_[i].y);
     std::printf("\n");
     for (size_t d = 0; d < m.defw_.size(); ++d) {
         std::printf("def %zu", d);

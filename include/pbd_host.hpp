@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "pbd.h"
+#include "pbd_bind.hpp"   // the ABI-calling bodies, shared with the OpenCV adapters (pbd_opencv_adapters.hpp)
 
 namespace pbdhost {
 
@@ -66,10 +67,18 @@ struct MatT {   // dense row-major matrix (the role cv::Mat_<T> plays at the ref
     const T *ptr(int r = 0) const { return data.data() + (size_t)r * cols; }
 };
 
-struct Image {   // 8-bit image view: rows x cols x channels, BGR interleaved when channels == 3
-    const uint8_t *data;
+struct Point {   // cv::Point at the reference's seams (Model::anchors, include/Model.hpp:66)
+    int x, y;
+    Point() : x(0), y(0) {}
+    Point(int x_, int y_) : x(x_), y(y_) {}
+};
+
+struct Image {   // image view: rows x cols x channels, BGR interleaved when channels == 3
+    const void *data;
     int rows, cols, channels;
-    size_t step;   // bytes between rows
+    size_t step;   // bytes between rows (cv::Mat::step)
+    int depth;     // cv::Mat::depth(): 0 = 8U, 2 = 16U, 5 = 32F, 6 = 64F (src/HOGFeatures.cpp:136-146)
+    Image() : data(NULL), rows(0), cols(0), channels(0), step(0), depth(0) {}
 };
 
 class Candidate {
@@ -121,11 +130,20 @@ public:
     int binsize_ = 4, flen_ = 32, norient_ = 18;
     std::vector<MatT<double> > filtersw_;
     std::vector<float> biasw_;
-    std::vector<std::pair<int, int> > anchors_;
+    std::vector<Point> anchors_;
     std::vector<std::vector<float> > defw_;
     std::vector<std::vector<std::vector<int> > > biasid_, filterid_, defid_;
     std::vector<std::vector<int> > parentid_;
 
+    // accessors named as the reference's (include/Model.hpp:99-121)
+    std::vector<MatT<double> > &filters() { return filtersw_; }
+    std::vector<float> &bias() { return biasw_; }
+    std::vector<std::vector<float> > &def() { return defw_; }
+    std::vector<Point> &anchors() { return anchors_; }
+    std::vector<std::vector<std::vector<int> > > &filterid() { return filterid_; }
+    std::vector<std::vector<std::vector<int> > > &biasid() { return biasid_; }
+    std::vector<std::vector<std::vector<int> > > &defid() { return defid_; }
+    std::vector<std::vector<int> > &parentid() { return parentid_; }
     std::string name() const { return name_; }
     float thresh() const { return thresh_; }
     int binsize() const { return binsize_; }
@@ -297,7 +315,15 @@ class FileStorageModel : public Model {
             text += t.substr(p, lt - p);
             p = lt;
             if (t.compare(p, 4, "<!--") == 0) { xml_skip(t, p); continue; }
-            if (t.compare(p, 2, "</") == 0) { p = t.find('>', p) + 1; break; }
+            if (t.compare(p, 2, "<?") == 0) { xml_skip(t, p); continue; }
+            if (t.compare(p, 2, "</") == 0) {
+                const size_t close = t.find('>', p);
+                if (close == std::string::npos) throw Error(PBD_ERR_INVALID, "model file: unterminated closing tag of <" + tag + ">");
+                if (trim_ws(t.substr(p + 2, close - p - 2)) != tag)
+                    throw Error(PBD_ERR_INVALID, "model file: <" + tag + "> closed by </" + trim_ws(t.substr(p + 2, close - p - 2)) + ">");
+                p = close + 1;
+                break;
+            }
             std::string ktag;
             Node kid = xml_element(t, p, ktag);
             kids.push_back(std::make_pair(ktag, kid));
@@ -367,7 +393,7 @@ public:
         biasw_.clear();
         { std::vector<double> b = doc["biasw"].nums(); biasw_.assign(b.begin(), b.end()); }
         anchors_.clear();
-        { std::vector<double> a = doc["anchors"].nums(); for (size_t k = 0; k + 1 < a.size(); k += 2) anchors_.push_back(std::make_pair((int)a[k], (int)a[k + 1])); }
+        { std::vector<double> a = doc["anchors"].nums(); for (size_t k = 0; k + 1 < a.size(); k += 2) anchors_.push_back(Point((int)a[k], (int)a[k + 1])); }
         defw_.clear();
         const Node &defs = doc["defs"];
         for (size_t d = 0; d < defs.seq.size(); ++d) { std::vector<double> w = defs.seq[d].nums(); defw_.push_back(std::vector<float>(w.begin(), w.end())); }
@@ -394,67 +420,47 @@ public:
     }
 };
 
-// flattened tables for pbd_create (include/Parts.hpp:172-187)
-struct FlatModel {
-    std::vector<int> ksize, part_offset, parentid, mix_offset, filterid, biasid, defid, anchors;
-    std::vector<int64_t> foff;
-    std::vector<float> filters32, biasw, defw;
-    std::vector<double> filters64;
-    pbd_model m;
-    explicit FlatModel(const Model &model)
-    {
-        int64_t off = 0;
-        for (size_t f = 0; f < model.filtersw_.size(); ++f) {
-            const MatT<double> &w = model.filtersw_[f];
-            ksize.push_back(w.rows);
-            foff.push_back(off);
-            filters64.insert(filters64.end(), w.data.begin(), w.data.end());
-            for (size_t i = 0; i < w.data.size(); ++i) filters32.push_back((float)w.data[i]);   // convertTo(T), src/PartsBasedDetector.cpp:114-117
-            off += (int64_t)w.data.size();
-        }
-        biasw = model.biasw_;
-        for (size_t d = 0; d < model.defw_.size(); ++d) {
-            for (int i = 0; i < 4; ++i) defw.push_back(model.defw_[d][i]);
-            anchors.push_back(model.anchors_[d].first);
-            anchors.push_back(model.anchors_[d].second);
-        }
-        part_offset.push_back(0);
-        mix_offset.push_back(0);
-        for (size_t c = 0; c < model.filterid_.size(); ++c) {
-            for (size_t p = 0; p < model.filterid_[c].size(); ++p) {
-                parentid.push_back(model.parentid_[c][p]);
-                const std::vector<int> &fid = model.filterid_[c][p], &bid = model.biasid_[c][p], &did = model.defid_[c][p];
-                for (size_t mm = 0; mm < fid.size(); ++mm) {
-                    filterid.push_back(fid[mm]);
-                    biasid.push_back(mm < bid.size() ? bid[mm] : -1);
-                    defid.push_back(p > 0 && mm < did.size() ? did[mm] : -1);
-                }
-                mix_offset.push_back(mix_offset.back() + (int)fid.size());
-            }
-            part_offset.push_back(part_offset.back() + (int)model.filterid_[c].size());
-        }
-        m.ncomponents = (int)model.filterid_.size();
-        m.nfilters = (int)ksize.size();
-        m.flen = model.flen_;
-        m.filter_ksize = ksize.data(); m.filter_offset = foff.data();
-        m.filters_f32 = filters32.data(); m.filters_f64 = filters64.data();
-        m.nbias = (int)biasw.size(); m.biasw = biasw.data();
-        m.ndefs = (int)(defw.size() / 4); m.defw = defw.data(); m.anchors = anchors.data();
-        m.part_offset = part_offset.data(); m.parentid = parentid.data(); m.mix_offset = mix_offset.data();
-        m.filterid = filterid.data(); m.biasid = biasid.data(); m.defid = defid.data();
-        m.thresh = model.thresh_; m.sbin = model.binsize_; m.interval = model.nscales_; m.norient = model.norient_;
-    }
-};
-
 // ---------------------------------------------------------------------------------------------- engines
-template <typename T> struct RealCode;
-template <> struct RealCode<float> { enum { value = PBD_REAL_F32 }; };
-template <> struct RealCode<double> { enum { value = PBD_REAL_F64 }; };
-
-inline void check(pbd_handle *h, int rc)
-{
-    if (rc != PBD_OK) throw Error(rc, std::string("pbd: ") + pbd_last_error(h));
-}
+// The traits pbd_bind.hpp's templates are instantiated with here (the OpenCV adapters supply the cv::Mat twin).
+template <typename T>
+struct HostTraits {
+    typedef T Real;
+    typedef MatT<T> Mat;
+    typedef MatT<int32_t> IMat;
+    typedef MatT<double> FilterMat;
+    typedef pbdhost::Image Image;
+    typedef pbdhost::Candidate Candidate;
+    static void create(Mat &m, int rows, int cols) { m = Mat(rows, cols); }
+    static T *ptr(Mat &m) { return m.ptr(); }
+    static const T *cptr(const Mat &m) { return m.ptr(); }
+    static int rows(const Mat &m) { return m.rows; }
+    static int cols(const Mat &m) { return m.cols; }
+    static void icreate(IMat &m, int rows, int cols) { m = IMat(rows, cols); }
+    static int32_t *iptr(IMat &m) { return m.ptr(); }
+    static Mat real_continuous(const Mat &m) { return m; }                 // MatT is always continuous T data
+    static Mat rows_view(Mat &m, int r0, int r1)
+    {   // MatT has no views: a copy
+        Mat r(r1 - r0, m.cols);
+        std::copy(m.ptr(r0), m.ptr(r0) + r.data.size(), r.data.begin());
+        return r;
+    }
+    static const void *img_data(const Image &im) { return im.data; }
+    static int img_rows(const Image &im) { return im.rows; }
+    static int img_cols(const Image &im) { return im.cols; }
+    static int img_channels(const Image &im) { return im.channels; }
+    static size_t img_step(const Image &im) { return im.step; }
+    static int img_depth(const Image &im) { return im.depth; }
+    static void fail(int rc, const std::string &text) { throw Error(rc, text); }
+    static void candidate(std::vector<Candidate> &out, const pbd_candidate_hdr &hd, const int32_t *r)
+    {
+        Candidate c;
+        c.component_ = hd.component; c.frame = hd.frame; c.level = hd.level; c.root_x = hd.root_x; c.root_y = hd.root_y;
+        for (int p = 0; p < hd.nparts; ++p) c.addPart(Rect(r[4 * p], r[4 * p + 1], r[4 * p + 2], r[4 * p + 3]), p == 0 ? hd.score : 0.0f);
+        out.push_back(c);
+    }
+    static int filter_rows(const FilterMat &w) { return w.rows; }
+    static void filter_values(const FilterMat &w, std::vector<double> &out) { out.insert(out.end(), w.data.begin(), w.data.end()); }
+};
 
 template <typename T>
 class HOGFeatures {   // IFeatures
@@ -465,17 +471,7 @@ public:
     size_t binsize() const { return (size_t)pbd_binsize(h_); }
     size_t nscales() const { return scales_.size(); }
     std::vector<float> scales() const { return scales_; }
-    void pyramid(const Image &im, std::vector<MatT<T> > &pyrafeatures)
-    {
-        int n = 0, fr[PBD_MAX_LEVELS], fc[PBD_MAX_LEVELS];
-        float sc[PBD_MAX_LEVELS];
-        check(h_, pbd_pyramid_plan(h_, im.rows, im.cols, &n, NULL, NULL, fr, fc, sc));
-        pyrafeatures.assign(n, MatT<T>());
-        std::vector<void *> ptrs(n);
-        for (int l = 0; l < n; ++l) { pyrafeatures[l] = MatT<T>(fr[l], fc[l] * 32); ptrs[l] = pyrafeatures[l].ptr(); }
-        check(h_, pbd_features_pyramid(h_, im.data, im.rows, im.cols, im.channels, im.step, 0, ptrs.data()));
-        scales_.assign(sc, sc + n);
-    }
+    void pyramid(const Image &im, std::vector<MatT<T> > &pyrafeatures) { pbdbind::pyramid<HostTraits<T> >(h_, im, pyrafeatures, scales_); }
 };
 
 template <typename T>
@@ -486,50 +482,15 @@ public:
     SpatialConvolutionEngine(pbd_handle *h, size_t nfilters) : h_(h), nfilters_(nfilters) {}
     void setFilters(const std::vector<MatT<T> > &filters)
     {
-        std::vector<const void *> ptrs(filters.size());
-        std::vector<int> ks(filters.size());
-        for (size_t f = 0; f < filters.size(); ++f) { ptrs[f] = filters[f].ptr(); ks[f] = filters[f].rows; }
-        check(h_, pbd_conv_set_filters(h_, (int)filters.size(), ptrs.data(), ks.data()));
+        pbdbind::set_filters<HostTraits<T> >(h_, filters);
         nfilters_ = filters.size();
     }
     // responses[level][filter] = H x W
     void pdf(const std::vector<MatT<T> > &features, std::vector<std::vector<MatT<T> > > &responses)
     {
-        const int M = (int)features.size();
-        std::vector<const void *> fp(M);
-        std::vector<void *> rp(M);
-        std::vector<int> rows(M), cols(M);
-        std::vector<std::vector<T> > packed(M);
-        for (int m = 0; m < M; ++m) {
-            rows[m] = features[m].rows; cols[m] = features[m].cols / 32;
-            fp[m] = features[m].ptr();
-            packed[m].resize((size_t)nfilters_ * rows[m] * cols[m]);
-            rp[m] = packed[m].data();
-        }
-        check(h_, pbd_conv_pdf(h_, M, fp.data(), rows.data(), cols.data(), rp.data()));
-        responses.assign(M, std::vector<MatT<T> >(nfilters_));
-        for (int m = 0; m < M; ++m)
-            for (size_t n = 0; n < nfilters_; ++n) {
-                MatT<T> r(rows[m], cols[m]);
-                std::copy(packed[m].begin() + n * r.data.size(), packed[m].begin() + (n + 1) * r.data.size(), r.data.begin());
-                responses[m][n] = r;
-            }
+        pbdbind::pdf<HostTraits<T> >(h_, nfilters_, features, responses);
     }
 };
-
-inline void unpack_candidates(pbd_handle *h, const std::vector<int32_t> &buf, int n, std::vector<Candidate> &out)
-{
-    const int stride = pbd_candidate_stride(h);
-    for (int i = 0; i < n; ++i) {
-        const int32_t *r = &buf[(size_t)i * stride];
-        const pbd_candidate_hdr *hd = reinterpret_cast<const pbd_candidate_hdr *>(r);
-        Candidate c;
-        c.component_ = hd->component; c.frame = hd->frame; c.level = hd->level; c.root_x = hd->root_x; c.root_y = hd->root_y;
-        for (int p = 0; p < hd->nparts; ++p)
-            c.addPart(Rect(r[8 + 4 * p], r[9 + 4 * p], r[10 + 4 * p], r[11 + 4 * p]), p == 0 ? hd->score : 0.0f);
-        out.push_back(c);
-    }
-}
 
 template <typename T>
 class DynamicProgram {
@@ -539,41 +500,13 @@ public:
     DynamicProgram(pbd_handle *h, int nfilters) : h_(h), nfilters_(nfilters) {}
     // scores[level][filter]; rootv/rooti[level][component]; the back-pointers stay on the device for argmin()
     void min(const std::vector<std::vector<MatT<T> > > &scores, std::vector<std::vector<MatT<T> > > &rootv,
-             std::vector<std::vector<MatT<int> > > &rooti, int ncomponents)
+             std::vector<std::vector<MatT<int32_t> > > &rooti, int ncomponents)
     {
-        const int M = (int)scores.size();
-        std::vector<int> rows(M), cols(M);
-        std::vector<std::vector<T> > packed(M), rv(M);
-        std::vector<std::vector<int32_t> > ri(M);
-        std::vector<const void *> sp(M);
-        std::vector<void *> rvp(M);
-        std::vector<int32_t *> rip(M);
-        for (int m = 0; m < M; ++m) {
-            rows[m] = scores[m][0].rows; cols[m] = scores[m][0].cols;
-            const size_t hw = (size_t)rows[m] * cols[m];
-            packed[m].resize(hw * nfilters_);
-            for (int f = 0; f < nfilters_; ++f) std::copy(scores[m][f].data.begin(), scores[m][f].data.end(), packed[m].begin() + f * hw);
-            rv[m].resize(hw * ncomponents); ri[m].resize(hw * ncomponents);
-            sp[m] = packed[m].data(); rvp[m] = rv[m].data(); rip[m] = ri[m].data();
-        }
-        check(h_, pbd_dp_min(h_, M, rows.data(), cols.data(), sp.data(), NULL, NULL, NULL, rvp.data(), rip.data()));
-        rootv.assign(M, std::vector<MatT<T> >(ncomponents));
-        rooti.assign(M, std::vector<MatT<int> >(ncomponents));
-        for (int m = 0; m < M; ++m)
-            for (int c = 0; c < ncomponents; ++c) {
-                const size_t hw = (size_t)rows[m] * cols[m];
-                rootv[m][c] = MatT<T>(rows[m], cols[m]);
-                rooti[m][c] = MatT<int>(rows[m], cols[m]);
-                std::copy(rv[m].begin() + c * hw, rv[m].begin() + (c + 1) * hw, rootv[m][c].data.begin());
-                std::copy(ri[m].begin() + c * hw, ri[m].begin() + (c + 1) * hw, rooti[m][c].data.begin());
-            }
+        pbdbind::dp_min<HostTraits<T> >(h_, nfilters_, ncomponents, scores, rootv, rooti);
     }
     void argmin(const std::vector<float> &scales, std::vector<Candidate> &candidates, int capacity = 1 << 16)
     {
-        std::vector<int32_t> buf((size_t)capacity * pbd_candidate_stride(h_));
-        int n = 0;
-        check(h_, pbd_dp_argmin(h_, scales.data(), buf.data(), capacity, &n));
-        unpack_candidates(h_, buf, n, candidates);
+        pbdbind::dp_argmin<HostTraits<T> >(h_, scales, candidates, capacity);
     }
 };
 
@@ -593,10 +526,7 @@ public:
     {   // src/PartsBasedDetector.cpp:102-127
         pbd_destroy(h_);
         h_ = NULL;
-        FlatModel fm(model);
-        pbd_config cfg = {device_, RealCode<T>::value, PBD_CONV_EXACT, 1, 1 << 18, NULL};
-        const int rc = pbd_create(&fm.m, &cfg, &h_);
-        if (rc != PBD_OK) throw Error(rc, std::string("pbd_create: ") + pbd_last_error(NULL));
+        h_ = pbdbind::create<HostTraits<T> >(model, device_, PBD_CONV_EXACT, 1, 1 << 18);
         name_ = model.name();
     }
     void detect(const Image &im, std::vector<Candidate> &candidates) { detect(im, Image(), candidates); }
@@ -604,11 +534,7 @@ public:
                 std::vector<Candidate> &candidates)
     {
         if (!h_) throw Error(PBD_ERR_STATE, "detect() before distributeModel()");
-        const int cap = 1 << 16;
-        std::vector<int32_t> buf((size_t)cap * pbd_candidate_stride(h_));
-        int n = 0;
-        check(h_, pbd_detect(h_, im.data, im.rows, im.cols, im.channels, im.step, buf.data(), cap, &n));
-        unpack_candidates(h_, buf, n, candidates);
+        pbdbind::detect<HostTraits<T> >(h_, im, candidates, 1 << 16);
     }
 };
 
@@ -625,7 +551,7 @@ inline bool readPNM(const std::string &path, std::vector<uint8_t> &pix, Image &i
     in.read(reinterpret_cast<char *>(pix.data()), (std::streamsize)pix.size());
     if (!in) return false;
     if (cn == 3) for (size_t i = 0; i < pix.size(); i += 3) std::swap(pix[i], pix[i + 2]);
-    im.data = pix.data(); im.rows = h; im.cols = w; im.channels = cn; im.step = (size_t)w * cn;
+    im.data = pix.data(); im.rows = h; im.cols = w; im.channels = cn; im.step = (size_t)w * cn; im.depth = 0;
     return true;
 }
 

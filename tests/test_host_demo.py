@@ -101,6 +101,21 @@ def test_cpp_reader_rejects_malformed_xml(demo, tmp_path):
     bad.write_text('<?xml version="1.0"?>\n<opencv_storage>\n<interval>5</interval>\n<thresh>0.</thresh>')   # unterminated
     r = subprocess.run([demo, str(bad), "--dump-model"], capture_output=True, text=True)
     assert r.returncode != 0 and "model file" in r.stderr
+    # a closing tag cut off before its '>' (used to restart the scan at offset 0 and recurse until the stack ran out)
+    bad.write_text('<?xml version="1.0"?>\n<opencv_storage>\n<interval>5</interval>\n<thresh>0.</thresh>\n</opencv_storage')
+    r = subprocess.run([demo, str(bad), "--dump-model"], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 254 and "unterminated closing tag" in r.stderr          # -2: a clean pbdhost::Error, not a crash
+    # a closing tag that does not match its opening tag
+    bad.write_text('<?xml version="1.0"?>\n<opencv_storage>\n<interval>5</thresh>\n</opencv_storage>')
+    r = subprocess.run([demo, str(bad), "--dump-model"], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 254 and "closed by" in r.stderr
+    # a processing instruction inside an element is skipped, not parsed as a child
+    ok = tmp_path / "pi.xml"
+    FS.serialize_xml(M.synthetic_tiny_model(thresh=0.5), str(ok))
+    text = ok.read_text().replace("<interval>", "<?note inside?>\n<interval>", 1)
+    ok.write_text(text)
+    r = subprocess.run([demo, str(ok), "--dump-model"], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 0 and "interval" in r.stdout, r.stderr
 
 
 @pytest.mark.gpu
@@ -140,6 +155,36 @@ def test_demo_nms_matches_python_mirror(demo, tmp_path):
     assert len(cands) == len(got) and 0 < len(got)
     assert sorted((c.level, c.root[1], c.root[0]) for c in cands) == sorted((k[0], k[2], k[3]) for k, _, _ in got)
     det.hd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [0.0, 0.1, 0.5])
+def test_demo_nms_against_a_painted_pixel_set(demo, tmp_path, overlap):
+    """Candidate::sort + nonMaximaSuppression of the C++ host (include/Candidate.hpp:91-111,277-304) on real detections,
+    against an INDEPENDENT formulation (not the Python mirror): the canvas is a set of painted (x, y) pixels, a box is the
+    set of image pixels inside the hull of the candidate's non-empty part rectangles."""
+    model = M.synthetic_person_model(thresh=17.9)
+    im = synth.synthetic_frame(21, 160, 120, 3)
+    rows, cols = im.shape[:2]
+    mpath, ipath = _write_inputs(tmp_path, model, im)
+    r = subprocess.run([demo, mpath, ipath], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    _, allc = _parse(r.stdout)                                   # sorted by score, descending, no suppression
+    r = subprocess.run([demo, mpath, ipath, "--nms", repr(overlap)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    _, got = _parse(r.stdout)
+    painted, want = set(), []
+    for key, score, parts in allc:
+        live = [tuple(int(v) for v in p) for p in parts if p[2] > 0 and p[3] > 0]
+        x1 = min(p[0] for p in live); y1 = min(p[1] for p in live)
+        x2 = max(p[0] + p[2] for p in live); y2 = max(p[1] + p[3] for p in live)
+        box = {(x, y) for x in range(max(x1, 0), min(x2, cols)) for y in range(max(y1, 0), min(y2, rows))}
+        if box and len(box & painted) / len(box) > overlap:
+            continue
+        painted |= box
+        want.append(key)
+    assert 0 < len(want) < len(allc) or overlap >= 0.5
+    assert [k for k, _, _ in got] == want
 
 
 @pytest.mark.parametrize("ext", ["yml", "xml"])

@@ -50,7 +50,7 @@ template <int MODE> double run(int waves_per_simd)
 {
     float *d; hipMalloc(&d, 4096);
     const int iters = 20000;
-    dim3 grid(256 * 4 * waves_per_simd / 4), block(256);     // 4 waves per block -> waves_per_simd per SIMD on 256 CUs
+    dim3 grid(256 * waves_per_simd), block(256);             // 4 waves per block (one per SIMD) -> waves_per_simd per SIMD on 256 CUs
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     hipLaunchKernelGGL(k<MODE>, grid, block, 0, 0, d, 10);
     hipDeviceSynchronize();
@@ -65,7 +65,7 @@ template <int MODE> double run(int waves_per_simd)
 }
 int main()
 {
-    for (int w = 1; w <= 2; ++w)
+    for (int w = 1; w <= 6; ++w)
         printf("waves/SIMD %d: add same-bank %.2f  add other-bank %.2f  mul same-bank %.2f  mul other-bank %.2f  cycles per instruction\n",
                w, run<0>(w), run<1>(w), run<2>(w), run<3>(w));
     return 0;
