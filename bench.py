@@ -64,6 +64,8 @@ def parse():
                     help="skip the run of the other convolution mode / the agreement check")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 rehearsal of the multi-GPU step: initialise torch.distributed (world size 1) and issue the RCCL all_gather of the device-resident candidate payload every step")
     return ap.parse_args()
 
 
@@ -103,8 +105,12 @@ def main():
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1])); s_.close()
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -127,49 +133,67 @@ def main():
     # gather payload: [count | cap_g records] per rank; latency-bound (KBs-MBs), ONE collective per step
     from partsbaseddetector_amd import dist as pdist
     # initial gather capacity in records (7.3 MB per rank for the person model); a batch with more candidates than
-    # this makes every rank grow its buffers and repeat the collective once -- it never raises (dist.CandidateGatherer)
+    # this makes every rank send a longer prefix of its payload once -- it never raises (dist.CandidateGatherer)
     cap_g = 16384
     dev = torch.device("cuda", local_rank)
-
-    gatherer = pdist.CandidateGatherer(stride, cap_g, dev if args.backend == "nccl" else "cpu") if world > 1 else None
-
+    on_device = use_dist and args.backend == "nccl"
+    gatherer = (pdist.CandidateGatherer(stride, cap_g, dev if on_device else "cpu", force_collective=args.force_collective, cap_full=cap)
+                if use_dist else None)
+    dgather = pdist.DeviceBatchGather(det, gatherer) if on_device else None
     gathered = [0]
+    ncand_last = [0]
 
-    def drain():
-        if gatherer is not None and gatherer.pending:
-            rec = gatherer.finish(root_only=True)                                      # rank 0 holds the whole list
-            gathered[0] = len(rec) if rec is not None else 0
+    def note(rec):
+        if rec is not None:
+            gathered[0] = len(rec)
 
-    def step():
-        # the candidate lists of batch k-1 are collected while batch k computes: begin() only packs the payload and issues
-        # the H2D copy and the (asynchronous) collective, finish() is called one step later, when it has long completed
-        buf, n = det.detect_batch_device(d_frames.data_ptr(), B, rows, cols, cn, raw=True)
-        if world > 1:
-            drain()
-            gatherer.begin(buf, n, frame_offset=rank * B)
-        return n
+    def run(steps):
+        """`steps` passes of the hot path over the resident batch, pipelined one batch deep: the host never waits for batch
+        k before batch k+1 is enqueued, so the candidates' read-back (N = 1) or gather (N > 1) of batch k runs under the
+        kernels of batch k+1.  Returns when every batch's candidate list is in host memory (rank 0: the gathered list)."""
+        if dgather is not None:
+            # N > 1 (RCCL): the candidate list never touches the host before the collective -- the walk kernel writes the
+            # [found | records] payload (global frame ids), all_gather_into_tensor reads a prefix of that tensor
+            for _ in range(steps):
+                note(dgather.submit(d_frames.data_ptr(), B, rows, cols, cn, frame_offset=rank * B, root_only=True))
+            note(dgather.collect(root_only=True))
+        elif gatherer is not None:
+            # gloo rehearsal: host records through the pinned staging buffer
+            for _ in range(steps):
+                buf, n = det.detect_batch_device(d_frames.data_ptr(), B, rows, cols, cn, raw=True)
+                if gatherer.pending:
+                    note(gatherer.finish(root_only=True))
+                gatherer.begin(buf, n, frame_offset=rank * B)
+                ncand_last[0] = n
+            note(gatherer.finish(root_only=True))
+        else:
+            det.submit_batch_device(d_frames.data_ptr(), B, rows, cols, cn)
+            for k in range(steps):
+                if k + 1 < steps:
+                    det.submit_batch_device(d_frames.data_ptr(), B, rows, cols, cn)
+                _, ncand_last[0] = det.wait_batch(raw=True)
 
     def sync():
-        drain()                                              # every issued gather is finished inside the timed region
         det.hd.check(det.hd.lib.pbd_synchronize(det.hd.h))
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup > 0:
+        run(args.warmup)
     if not args.no_profile:
         det.hd.profile(True)
     sync()
     t0 = time.perf_counter()
-    ncand = 0
-    for _ in range(args.steps):
-        ncand = step()
+    run(args.steps)
     sync()
     dt = time.perf_counter() - t0
+    if dgather is not None:
+        ncand_last[0] = gathered[0]
+    ncand = ncand_last[0]
     rank_ms = [dt / args.steps * 1e3]
-    if world > 1:
+    if use_dist:
         mine = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -275,7 +299,7 @@ def main():
                    "stage_ms_per_frame": {k: round(v, 2) for k, v in stage.items()},
                    "single_thread": {"value": round(1.0 / c1, 4), "unit": "detections/s", "cores": 1, "sample": "1 frame"}}
         other_mode, agreement = None, None
-        if world == 1 and args.conv_mode in ("exact", "mfma") and not args.no_other:
+        if world == 1 and not use_dist and args.conv_mode in ("exact", "mfma") and not args.no_other:
             # the other convolution mode on the same resident batch: exact <-> matrix cores
             oname = "mfma" if args.conv_mode == "exact" else "exact"
             last = np.array(det._buf[:ncand * stride]).reshape(ncand, stride).copy()
@@ -309,7 +333,7 @@ def main():
                          "records_identical": bool(len(odd) == 0 and boxes_same == len(common))}
             det2.hd.close()
         host_input = None
-        if world == 1 and not args.no_other:
+        if world == 1 and not use_dist and not args.no_other:
             # SURVEY 8(d)'s end-to-end form of the metric: frames in (pageable) HOST memory -> candidate lists in host
             # memory.  The pipelined entry points keep two batches in flight, so the host-side staging and the PCIe copy of
             # batch k+1 overlap the kernels of batch k.  Reported beside `value` (which, per the bench contract, is
@@ -355,11 +379,13 @@ def main():
                                    f"5x5x32), batch of {B} {cols}x{rows} frames per GPU, full HOG+conv+DT/DP+argmin on GPU",
                        "frames_per_gpu_per_step": B, "conv_mode": args.conv_mode, "candidates_last_step": int(gathered[0] if world > 1 else ncand),
                        "parallelism": f"frames sharded over {world} GPU(s), RCCL all_gather of candidates",
-                       "world_size": dist.get_world_size() if world > 1 else 1,
-                       "backend": dist.get_backend() if world > 1 else None,
+                       "world_size": dist.get_world_size() if use_dist else 1,
+                       "backend": dist.get_backend() if use_dist else None,
+                       "pipeline": "one batch deep: batch k+1 is enqueued before the candidate list of batch k is collected",
                        "rank_ms_per_step": [round(v, 3) for v in rank_ms],
                        "gather": ({"collectives_per_step": gatherer.collectives / max(args.steps + args.warmup, 1),
                                    "capacity_records": gatherer.cap, "grown": gatherer.grown,
+                                   "payload": "device-resident: written by the walk kernel, handed to all_gather_into_tensor as it is" if on_device else "host records (gloo rehearsal)",
                                    "overlap": "the collective of batch k runs under the kernels of batch k+1 (begin / finish one step apart)"} if gatherer else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": stage_ms,
             "roofline_all": roof_all,
@@ -368,7 +394,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     det.hd.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

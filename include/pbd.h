@@ -74,7 +74,12 @@ enum { PBD_CONV_EXACT = 0,   /* multiply and add rounded separately in the refer
        PBD_CONV_MFMA = 2,    /* matrix cores, bf16 hi/lo operand split (3 MFMAs per product tile), fp32 accumulation:
                                 responses within 1e-4 (~1e-6 observed), not bit-identical; 5x5 filters, PBD_REAL_F32 only */
        PBD_CONV_MFMA_F16 = 3 }; /* matrix cores, operands rounded once to fp16 (1 MFMA per product tile), fp32 accumulation:
-                                the 1e-4 bar does not hold (~1e-3 observed on unit-scale scores); same restrictions */
+                                the 1e-4 bar does not hold (~1e-3 observed on unit-scale scores); same restrictions.
+                                In this mode the RESPONSES live on the device as fp16 (BASELINE configs[4] "fp16 responses"):
+                                pbd_conv_pdf returns them widened to float, |v| >= 65520 saturates to +-inf, and pbd_dp_min
+                                ROUNDS THE CALLER'S float scores to fp16 before the dynamic program (exact for scores that
+                                came from pbd_conv_pdf; arbitrary scores lose precision: tests/test_gpu_parity.py::
+                                test_mfma_f16_dp_min_rounds_its_input pins this) */
 
 typedef struct pbd_config {
     int device;            /* HIP device ordinal */
@@ -118,7 +123,8 @@ int pbd_pyramid_plan(pbd_handle *h, int rows, int cols, int *nlevels, int *img_r
 /* IFeatures::pyramid(im, pyrafeatures): feat[l] receives feat_rows[l] x (feat_cols[l]*flen) values of T.
  * stride_bytes: byte distance between image rows (cv::Mat::step).  depth_code = cv::Mat::depth() of the image: 0 (CV_8U),
  * 2 (CV_16U), 5 (CV_32F) or 6 (CV_64F) -- the four features<IT> instantiations of src/HOGFeatures.cpp:136-146; any other
- * depth fails with PBD_ERR_UNSUPPORTED as the reference's CV_Error. */
+ * depth fails with PBD_ERR_UNSUPPORTED as the reference's CV_Error.  A 32F / 64F image holding a NaN or Inf pixel is
+ * refused with PBD_ERR_INVALID (here and in pbd_detect_typed): non-finite input is an error, not a silently different result. */
 int pbd_features_pyramid(pbd_handle *h, const void *img, int rows, int cols, int channels,
                          size_t stride_bytes, int depth_code, void *const *feat);
 /* the resampled level images of the last pbd_features_pyramid / pbd_detect call (for tests) */
@@ -151,7 +157,10 @@ int pbd_dp_min(pbd_handle *h, int nlevels, const int *rows, const int *cols, con
                int32_t *const *rooti);
 /* argmin(parts, rootv, rooti, scales, Ix, Iy, Ik, candidates) (src/DynamicProgram.cpp:190-255) on
  * the device-resident result of the last pbd_dp_min / pbd_detect*.  Candidates are written sorted by
- * (frame, level, component, root_y, root_x) (the reference's order is nondeterministic, :246-251). */
+ * (frame, level, component, root_y, root_x): the raster order of the reference's Math::find per (level, component)
+ * (:208-216); its order ACROSS levels is nondeterministic (#pragma omp critical, :246-251).  The order is produced on the
+ * device (ordered compaction, no sort); when more than `capacity` are found, the first `capacity` of that order are
+ * returned with PBD_ERR_CAPACITY. */
 int pbd_dp_argmin(pbd_handle *h, const float *scales, int32_t *cand, int capacity, int *ncand);
 
 /* ---- PartsBasedDetector<T>::detect (include/PartsBasedDetector.hpp:172-173, src/PartsBasedDetector.cpp:69-95).
@@ -175,10 +184,30 @@ int pbd_detect_batch(pbd_handle *h, int nframes, const void *const *imgs, int ro
 int pbd_detect_batch_submit(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int channels,
                             size_t stride_bytes);
 int pbd_detect_batch_wait(pbd_handle *h, int32_t *cand, int capacity, int *ncand);
+/* submit() for frames already resident in device memory (d_frames as in pbd_detect_batch_device; they must stay
+ * untouched until the matching wait() returns): nothing is copied in, the candidates' read-back of batch k overlaps the
+ * kernels of batch k+1. */
+int pbd_detect_batch_device_submit(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels);
 /* Same, frames already resident in device memory: d_frames = nframes contiguous rows*cols*channels
  * images.  cand is a HOST buffer. */
 int pbd_detect_batch_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels,
                             int32_t *cand, int capacity, int *ncand);
+
+/* Device-resident output (new surface: multi-GPU jobs, device pipelines).  The candidate list stays on the device in the
+ * caller's buffer d_payload = int32[1 + capacity * pbd_candidate_stride()] ("payload"):
+ *   word 0      number of candidates FOUND -- may exceed `capacity`; then only the first `capacity` of the order are present
+ *   word 1...   min(found, capacity) records, sorted by (frame, level, component, root_y, root_x); `frame` = frame_offset +
+ *               index in the batch (frames sharded over GPUs: the global frame id)
+ * i.e. exactly what a rank contributes to the one gather of Candidate lists per batch (partsbaseddetector_amd/dist.py hands
+ * this buffer to all_gather_into_tensor as it is; nothing passes through the host).  ASYNCHRONOUS: the call returns once
+ * the work is enqueued on pbd_stream(); order later work behind that stream (or call pbd_synchronize).
+ * pbd_argmin_device_out re-emits the list of the batch still resident from the last pbd_detect* call -- used after a
+ * capacity overflow (word 0 > capacity) with a larger buffer; the dynamic program is not run again. */
+int pbd_detect_batch_device_out(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels,
+                                int frame_offset, int32_t *d_payload, int capacity);
+int pbd_argmin_device_out(pbd_handle *h, int frame_offset, int32_t *d_payload, int capacity);
+/* the hipStream_t every kernel of this handle runs on (pbd_config.stream, or the library's own) */
+void *pbd_stream(const pbd_handle *h);
 
 /* ---- staged read-back of the last pbd_detect* call (tests, profiling) ---- */
 enum { PBD_STAGE_FEATURES = 0, PBD_STAGE_RESPONSES = 1, PBD_STAGE_ROOTV = 2, PBD_STAGE_ROOTI = 3 };

@@ -29,7 +29,8 @@ SYMBOLS = [
     "pbd_create", "pbd_destroy", "pbd_last_error", "pbd_version", "pbd_candidate_stride", "pbd_binsize",
     "pbd_pyramid_plan", "pbd_set_level_shard", "pbd_features_pyramid", "pbd_get_pyramid_image", "pbd_conv_set_filters", "pbd_conv_pdf",
     "pbd_num_ptr_slots", "pbd_ptr_slot", "pbd_dp_min", "pbd_dp_argmin", "pbd_detect", "pbd_detect_batch",
-    "pbd_detect_batch_device", "pbd_detect_typed", "pbd_detect_batch_submit", "pbd_detect_batch_wait", "pbd_get_stage", "pbd_profile_enable", "pbd_profile_reset", "pbd_profile_read",
+    "pbd_detect_batch_device", "pbd_detect_typed", "pbd_detect_batch_submit", "pbd_detect_batch_wait",
+    "pbd_detect_batch_device_submit", "pbd_detect_batch_device_out", "pbd_argmin_device_out", "pbd_stream", "pbd_get_stage", "pbd_profile_enable", "pbd_profile_reset", "pbd_profile_read",
     "pbd_kernel_name", "pbd_synchronize",
 ]
 
@@ -105,6 +106,11 @@ def load():
     lib.pbd_detect_batch_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     lib.pbd_detect_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_int, C.POINTER(C.c_int)]
+    lib.pbd_detect_batch_device_submit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.pbd_detect_batch_device_out.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.pbd_argmin_device_out.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.pbd_stream.argtypes = [C.c_void_p]
+    lib.pbd_stream.restype = C.c_void_p
     lib.pbd_get_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.pbd_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.pbd_profile_read.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]

@@ -229,14 +229,25 @@ struct pbd_handle {
     // workspace
     DevBuf frames, pyr, gmag, gori, hist, norm, feat, resp, acc, Ik, rootv, rooti;
     int totmix = 0;                  // (part, mixture) pairs of the model = planes of IxRaw / IyRaw per cell block
-    DevBuf tmp, dt, IxRaw, IyRaw, stk, cand, count, scales_tmp;
-    std::vector<int32_t> cand_host;
+    DevBuf tmp, dt, IxRaw, IyRaw, stk, scales_tmp, find_blk;
+
+    // A candidate list on its way out.  The device side is the "payload" the find / walk kernels write: word 0 = roots
+    // found, then the records, already in (frame, level, component, y, x) order.  The host side is a pinned mirror: the
+    // count and the first `guess` records (what the previous batch needed + 25 %) are copied by ONE asynchronous D2H
+    // enqueued right behind the walk kernel, so a steady stream of batches never waits for a count before it can ask for
+    // the records; a batch that outgrows the guess costs one more copy.
+    struct CandBuf {
+        DevBuf payload;
+        int32_t *host = nullptr; size_t host_words = 0;
+        int guess = 1024;
+        int copied = 0;                                   // records covered by the enqueued copy
+    } cb;
 
     // pipelined host entry points (pbd_detect_batch_submit / _wait): two batches may be in flight
     struct Slot {
         void *pinned = nullptr; size_t pinned_cap = 0;   // host staging of the frames (hipHostMalloc)
-        DevBuf frames, cand, count;
-        int *count_host = nullptr;                        // pinned
+        DevBuf frames;
+        CandBuf cb;
         hipEvent_t copied = nullptr, done = nullptr;
         Plan *plan = nullptr;
         int nframes = 0;
@@ -629,10 +640,19 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         if (std::find(sizes.begin(), sizes.end(), ksize[f]) == sizes.end()) sizes.push_back(ksize[f]);
     const int K = ksize[0];
     const bool fast = (sizeof(R) == 4 && K == 5 && sizes.size() == 1);
-    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); }
-    h->conv_classes.assign(sizes.size(), pbd_handle::ConvClass{});
+    const bool mfma = h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16;
+    if (mfma && !fast) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA / PBD_CONV_MFMA_F16 need 5x5 filters and PBD_REAL_F32");
+    // The new bank is built beside the old one and swapped in only when every upload has succeeded: a failed setFilters()
+    // (out of memory, an unsupported size) leaves the handle with its previous, complete bank.
+    struct NewBank {
+        std::vector<pbd_handle::ConvClass> classes;
+        DevBuf wrec;
+        bool keep = false;
+        ~NewBank() { if (!keep) { for (auto &c : classes) { c.wts.release(); c.fmap.release(); } wrec.release(); } }
+    } nb;
+    nb.classes.assign(sizes.size(), pbd_handle::ConvClass{});
     for (size_t ci = 0; ci < sizes.size(); ++ci) {
-        pbd_handle::ConvClass &C = h->conv_classes[ci];
+        pbd_handle::ConvClass &C = nb.classes[ci];
         C.K = sizes[ci];
         std::vector<int> ids;
         for (int f = 0; f < nfilters; ++f) if (ksize[f] == C.K) ids.push_back(f);
@@ -657,8 +677,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         if (sizes.size() > 1) HIPCHK(h, C.fmap.upload(ids));
     }
     const int Fpad = (nfilters + kConvQ - 1) / kConvQ * kConvQ;
-    if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16) {
-        if (!fast) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA / PBD_CONV_MFMA_F16 need 5x5 filters and PBD_REAL_F32");
+    if (mfma) {
         const bool f16 = h->cfg.conv_mode == PBD_CONV_MFMA_F16;
         // bf16 mode: x = hi + lo with round-to-nearest-even; fp16 mode: one rounding
         auto f2bf = [](float f) -> uint16_t {
@@ -690,9 +709,15 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
                                 rec[base + (size_t)(64 + lane) * 8 + j] = f2bf(v - bf2f(hi));
                             }
                         }
-        HIPCHK(h, h->d_wrec.ensure(rec.size() * 2));
-        HIPCHK(h, hipMemcpy(h->d_wrec.p, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(h, nb.wrec.ensure(rec.size() * 2));
+        HIPCHK(h, hipMemcpy(nb.wrec.p, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
     }
+    // commit
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); }
+    h->conv_classes.swap(nb.classes);
+    nb.classes.clear();
+    if (mfma) { h->d_wrec.release(); h->d_wrec = nb.wrec; nb.wrec = DevBuf{}; }
+    nb.keep = true;
     h->F = nfilters; h->Fpad = Fpad; h->ksize = K;
     h->filter_ksize.assign(ksize, ksize + nfilters);
     h->filters_set = true;
@@ -1124,7 +1149,11 @@ int run_dp(pbd_handle *h, Plan &P, int nframes)
     return PBD_OK;
 }
 
-ArgminParams argmin_params(pbd_handle *h, Plan &P, int nframes, const float *d_scales, DevBuf &cand, DevBuf &count)
+// ---- argmin: find (ordered compaction) + walk into a device payload, then one D2H ---------------------------------
+// enqueues the find and walk kernels for the `nframes` frames of the device-resident DP result; the candidate list is
+// written to d_payload = int32[1 + capacity * stride] (see pbd_handle::CandBuf).  No host synchronisation.
+int enqueue_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int frame_offset, int32_t *d_payload,
+                   int capacity, hipStream_t st)
 {
     ArgminParams ap{};
     ap.lv = P.d_lv.d; ap.nlevels = P.nlevels; ap.NS = h->NS; ap.NC = h->NC; ap.nframes = nframes;
@@ -1133,32 +1162,60 @@ ArgminParams argmin_params(pbd_handle *h, Plan &P, int nframes, const float *d_s
     ap.IxRaw = h->IxRaw.p; ap.IyRaw = h->IyRaw.p; ap.NJ = h->totmix; ap.Ik = h->Ik.as<uint8_t>(); ap.ptr8 = P.ptr8 ? 1 : 0;
     ap.thresh = h->thresh; ap.scales = d_scales;
     ap.walk = h->d_walk.d; ap.walk_off = h->d_walk_off.d;
-    ap.max_parts = h->max_parts; ap.stride = 8 + 4 * h->max_parts; ap.capacity = std::max(h->cfg.max_candidates, 1);
-    ap.count = count.as<int>(); ap.cand = cand.as<int32_t>();
-    return ap;
+    ap.max_parts = h->max_parts; ap.stride = 8 + 4 * h->max_parts; ap.capacity = std::max(capacity, 0);
+    ap.payload = d_payload; ap.frame_offset = frame_offset;
+    ap.ntotal = (long long)nframes * P.cell_per_frame * h->NC;
+    ap.nblk = (int)std::max<long long>((ap.ntotal + argmin_find_span() - 1) / argmin_find_span(), 1);
+    HIPCHK(h, h->find_blk.ensure((size_t)ap.nblk * sizeof(int)));
+    ap.blk = h->find_blk.as<int>();
+    ProfScope ps(h, PBD_K_ARGMIN, st);
+    launch_argmin_find(ap, h->f64, st);
+    launch_argmin_walk(ap, h->f64, st);
+    return PBD_OK;
 }
 
-// the host half of argmin: `n` records in h->cand_host -> total order (frame, level, component, y, x) -> caller's buffer
-// (the reference's order is nondeterministic: src/DynamicProgram.cpp:246-251)
-int argmin_deliver(pbd_handle *h, int found, int32_t *cand, int capacity, int *ncand)
+int candbuf_host(pbd_handle *h, pbd_handle::CandBuf &cb, size_t words)
 {
-    const int stride = 8 + 4 * h->max_parts;
-    const int cap = std::max(h->cfg.max_candidates, 1);
+    if (cb.host_words >= words) return PBD_OK;
+    if (cb.host) { (void)hipHostFree(cb.host); cb.host = nullptr; cb.host_words = 0; }
+    const size_t want = words + words / 4 + 256;
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&cb.host), want * sizeof(int32_t), hipHostMallocDefault));
+    cb.host_words = want;
+    return PBD_OK;
+}
+
+// find + walk into cb.payload and the speculative read-back of [count | first records], all on `st`
+int enqueue_argmin_readback(pbd_handle *h, Plan &P, int nframes, const float *d_scales, pbd_handle::CandBuf &cb, hipStream_t st)
+{
+    const int stride = 8 + 4 * h->max_parts, cap = std::max(h->cfg.max_candidates, 1);
+    HIPCHK(h, cb.payload.ensure(((size_t)cap * stride + 1) * sizeof(int32_t)));
+    int rc = enqueue_argmin(h, P, nframes, d_scales, 0, cb.payload.as<int32_t>(), cap, st);
+    if (rc != PBD_OK) return rc;
+    cb.copied = std::min(cb.guess, cap);
+    const size_t words = 1 + (size_t)cb.copied * stride;
+    if ((rc = candbuf_host(h, cb, words)) != PBD_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(cb.host, cb.payload.p, words * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    return PBD_OK;
+}
+
+// after the read-back has completed: hand the records to the caller (the reference's order is nondeterministic,
+// src/DynamicProgram.cpp:246-251; here it is (frame, level, component, y, x), produced on the device)
+int argmin_deliver(pbd_handle *h, pbd_handle::CandBuf &cb, hipStream_t st, int32_t *cand, int capacity, int *ncand)
+{
+    const int stride = 8 + 4 * h->max_parts, cap = std::max(h->cfg.max_candidates, 1);
+    const int found = cb.host[0];
     const int n = std::min(found, cap);
-    std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    const int32_t *ch = h->cand_host.data();
-    std::sort(order.begin(), order.end(), [&](int a, int b) {
-        const int32_t *A = ch + (size_t)a * stride, *B = ch + (size_t)b * stride;
-        if (A[0] != B[0]) return A[0] < B[0];
-        if (A[2] != B[2]) return A[2] < B[2];
-        if (A[1] != B[1]) return A[1] < B[1];
-        if (A[4] != B[4]) return A[4] < B[4];
-        return A[3] < B[3];
-    });
-    const int nout = std::min(n, capacity);
-    for (int i = 0; i < nout; ++i)
-        memcpy(cand + (size_t)i * stride, ch + (size_t)order[i] * stride, (size_t)stride * sizeof(int32_t));
+    if (n > cb.copied) {     // more candidates than the speculative copy covered: fetch the list again, whole
+        const size_t words = 1 + (size_t)n * stride;
+        const int rc = candbuf_host(h, cb, words);
+        if (rc != PBD_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(cb.host, cb.payload.p, words * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        cb.copied = n;
+    }
+    cb.guess = std::min(cap, n + n / 4 + 256);
+    const int nout = std::min(n, std::max(capacity, 0));
+    if (nout > 0) memcpy(cand, cb.host + 1, (size_t)nout * stride * sizeof(int32_t));
     *ncand = nout;
     if (found > cap || n > capacity)
         return fail(h, PBD_ERR_CAPACITY, "%d candidates found, capacity %d (config max_candidates %d)", found, capacity, cap);
@@ -1167,32 +1224,11 @@ int argmin_deliver(pbd_handle *h, int found, int32_t *cand, int capacity, int *n
 
 int run_argmin(pbd_handle *h, Plan &P, int nframes, const float *d_scales, int32_t *cand, int capacity, int *ncand)
 {
-    const int stride = 8 + 4 * h->max_parts;
-    const int cap = std::max(h->cfg.max_candidates, 1);
-    HIPCHK(h, h->cand.ensure((size_t)cap * stride * sizeof(int32_t)));
-    HIPCHK(h, h->count.ensure(sizeof(int)));
-    HIPCHK(h, hipMemsetAsync(h->count.p, 0, sizeof(int), h->stream));
-    const ArgminParams ap = argmin_params(h, P, nframes, d_scales, h->cand, h->count);
-    int found = 0;
-    {
-        ProfScope ps(h, PBD_K_ARGMIN, h->stream);
-        launch_argmin_find(ap, h->f64, h->stream);
-    }
-    HIPCHK(h, hipMemcpyAsync(&found, h->count.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    const int rc = enqueue_argmin_readback(h, P, nframes, d_scales, h->cb, h->stream);
+    if (rc != PBD_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int n = std::min(found, cap);
-    if (n > 0) {
-        {
-            ProfScope ps(h, PBD_K_ARGMIN, h->stream);
-            launch_argmin_walk(ap, n, h->f64, h->stream);
-        }
-        h->cand_host.resize((size_t)n * stride);
-        HIPCHK(h, hipMemcpyAsync(h->cand_host.data(), h->cand.p, (size_t)n * stride * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                 h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
     HIPCHK(h, hipGetLastError());
-    return argmin_deliver(h, found, cand, capacity, ncand);
+    return argmin_deliver(h, h->cb, h->stream, cand, capacity, ncand);
 }
 
 // enqueues pyramid -> HOG -> convolution -> dynamic program for the batch (no host synchronisation); *plan_out = its plan
@@ -1267,6 +1303,21 @@ int upload_frames(pbd_handle *h, int nframes, const void *const *imgs, int rows,
 {
     const size_t row_bytes = (size_t)cols * cn * depth_size(h->cur_depth);
     if (stride_bytes < row_bytes) return fail(h, PBD_ERR_INVALID, "stride %zu < row bytes %zu", stride_bytes, row_bytes);
+    // 32F / 64F images: a NaN or Inf pixel is refused.  The reference computes *something* deterministic from one (NaN
+    // gradients, NaN histogram bins, NaN responses whose envelope read-out order then matters); the distance transform here
+    // walks the envelope top-down, which equals the reference's bottom-up walk only for strictly increasing finite
+    // intersections -- so non-finite input is defined as an error instead of being allowed to differ silently.
+    if (h->cur_depth == kDepth32F || h->cur_depth == kDepth64F) {
+        const size_t n = (size_t)cols * cn;
+        for (int i = 0; i < nframes; ++i)
+            for (int y = 0; y < rows; ++y) {
+                const char *row = static_cast<const char *>(imgs[i]) + (size_t)y * stride_bytes;
+                bool ok = true;
+                if (h->cur_depth == kDepth32F) { const float *p = reinterpret_cast<const float *>(row); for (size_t k = 0; k < n; ++k) ok = ok && std::isfinite(p[k]); }
+                else { const double *p = reinterpret_cast<const double *>(row); for (size_t k = 0; k < n; ++k) ok = ok && std::isfinite(p[k]); }
+                if (!ok) return fail(h, PBD_ERR_INVALID, "frame %d, row %d holds a NaN or Inf pixel", i, y);
+            }
+    }
     HIPCHK(h, h->frames.ensure((size_t)nframes * rows * row_bytes + 4));
     for (int i = 0; i < nframes; ++i)
         HIPCHK(h, hipMemcpy2DAsync(h->frames.as<uint8_t>() + (size_t)i * rows * row_bytes, row_bytes, imgs[i], stride_bytes,
@@ -1367,17 +1418,19 @@ void pbd_destroy(pbd_handle *h)
     if (h->stream_d2h) (void)hipStreamSynchronize(h->stream_d2h);
     for (pbd_handle::Slot &S : h->slot) {
         if (S.pinned) (void)hipHostFree(S.pinned);
-        if (S.count_host) (void)hipHostFree(S.count_host);
+        if (S.cb.host) (void)hipHostFree(S.cb.host);
         if (S.copied) (void)hipEventDestroy(S.copied);
         if (S.done) (void)hipEventDestroy(S.done);
-        S.frames.release(); S.cand.release(); S.count.release();
+        S.frames.release(); S.cb.payload.release();
     }
+    if (h->cb.host) (void)hipHostFree(h->cb.host);
+    h->cb.payload.release();
     if (h->stream_copy) (void)hipStreamDestroy(h->stream_copy);
     if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
     for (auto e : h->chunk_events) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (DevBuf *b : {&h->frames, &h->pyr, &h->gmag, &h->gori, &h->hist, &h->norm, &h->feat, &h->resp, &h->acc, &h->Ik, &h->rootv,
-                      &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->cand, &h->count,
+                      &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->find_blk,
                       &h->scales_tmp})
         b->release();
     for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); }
@@ -1670,6 +1723,23 @@ int pbd_detect_batch(pbd_handle *h, int nframes, const void *const *imgs, int ro
     });
 }
 
+// what submit() does once the frames of the batch are (being) made resident at d_frames: the whole path, the candidates'
+// read-back and the slot's completion event, all enqueued on the handle's stream without waiting
+static int submit_enqueue(pbd_handle *h, pbd_handle::Slot &S, int nframes, const void *d_frames, int rows, int cols, int channels)
+{
+    if (!S.done) HIPCHK(h, hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+    Plan *P = nullptr;
+    h->cur_depth = kDepth8U;
+    int rc = enqueue_detect(h, nframes, d_frames, rows, cols, channels, &P);
+    if (rc != PBD_OK) return rc;
+    if ((rc = enqueue_argmin_readback(h, *P, nframes, P->d_scales.d, S.cb, h->stream)) != PBD_OK) return rc;
+    HIPCHK(h, hipEventRecord(S.done, h->stream));
+    HIPCHK(h, hipGetLastError());
+    S.plan = P; S.nframes = nframes;
+    h->nsubmitted += 1;
+    return PBD_OK;
+}
+
 int pbd_detect_batch_submit(pbd_handle *h, int nframes, const void *const *imgs, int rows, int cols, int channels,
                             size_t stride_bytes)
 {
@@ -1684,19 +1754,13 @@ int pbd_detect_batch_submit(pbd_handle *h, int nframes, const void *const *imgs,
         if (stride_bytes < row_bytes) return fail(h, PBD_ERR_INVALID, "stride %zu < row bytes %zu", stride_bytes, row_bytes);
         pbd_handle::Slot &S = h->slot[h->nsubmitted & 1];
         if (!h->stream_copy) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
-        if (!h->stream_d2h) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
         if (!S.copied) HIPCHK(h, hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
-        if (!S.done) HIPCHK(h, hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
-        if (!S.count_host) HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&S.count_host), sizeof(int), hipHostMallocDefault));
         if (S.pinned_cap < bytes) {
             if (S.pinned) { (void)hipHostFree(S.pinned); S.pinned = nullptr; S.pinned_cap = 0; }
             HIPCHK(h, hipHostMalloc(&S.pinned, bytes + bytes / 8, hipHostMallocDefault));
             S.pinned_cap = bytes + bytes / 8;
         }
         HIPCHK(h, S.frames.ensure(bytes));
-        const int stride = 8 + 4 * h->max_parts, cap = std::max(h->cfg.max_candidates, 1);
-        HIPCHK(h, S.cand.ensure((size_t)cap * stride * sizeof(int32_t)));
-        HIPCHK(h, S.count.ensure(sizeof(int)));
         // host staging (this is what overlaps the kernels of the batch submitted before), then one asynchronous copy
         for (int i = 0; i < nframes; ++i) {
             char *dst = static_cast<char *>(S.pinned) + (size_t)i * frame_bytes;
@@ -1707,23 +1771,17 @@ int pbd_detect_batch_submit(pbd_handle *h, int nframes, const void *const *imgs,
         HIPCHK(h, hipMemcpyAsync(S.frames.p, S.pinned, bytes, hipMemcpyHostToDevice, h->stream_copy));
         HIPCHK(h, hipEventRecord(S.copied, h->stream_copy));
         HIPCHK(h, hipStreamWaitEvent(h->stream, S.copied, 0));
-        Plan *P = nullptr;
-        h->cur_depth = kDepth8U;
-        int rc = enqueue_detect(h, nframes, S.frames.p, rows, cols, channels, &P);
-        if (rc != PBD_OK) return rc;
-        HIPCHK(h, hipMemsetAsync(S.count.p, 0, sizeof(int), h->stream));
-        const ArgminParams ap = argmin_params(h, *P, nframes, P->d_scales.d, S.cand, S.count);
-        {
-            ProfScope ps(h, PBD_K_ARGMIN, h->stream);
-            launch_argmin_find(ap, h->f64, h->stream);
-            launch_argmin_walk(ap, -1, h->f64, h->stream);     // count read on the device
-        }
-        HIPCHK(h, hipMemcpyAsync(S.count_host, S.count.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipEventRecord(S.done, h->stream));
-        HIPCHK(h, hipGetLastError());
-        S.plan = P; S.nframes = nframes;
-        h->nsubmitted += 1;
-        return PBD_OK;
+        return submit_enqueue(h, S, nframes, S.frames.p, rows, cols, channels);
+    });
+}
+
+int pbd_detect_batch_device_submit(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels)
+{
+    return guarded(h, [&]() -> int {
+        if (!h || !d_frames) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (h->nsubmitted - h->nwaited >= 2) return fail(h, PBD_ERR_STATE, "two batches are already in flight: call pbd_detect_batch_wait first");
+        return submit_enqueue(h, h->slot[h->nsubmitted & 1], nframes, d_frames, rows, cols, channels);
     });
 }
 
@@ -1736,17 +1794,49 @@ int pbd_detect_batch_wait(pbd_handle *h, int32_t *cand, int capacity, int *ncand
         pbd_handle::Slot &S = h->slot[h->nwaited & 1];
         h->nwaited += 1;                       // the slot is released whatever happens below
         HIPCHK(h, hipEventSynchronize(S.done));
-        const int stride = 8 + 4 * h->max_parts, cap = std::max(h->cfg.max_candidates, 1);
-        const int found = *S.count_host, n = std::min(found, cap);
-        h->cand_host.resize((size_t)n * stride);
-        if (n > 0) {
-            HIPCHK(h, hipMemcpyAsync(h->cand_host.data(), S.cand.p, (size_t)n * stride * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                     h->stream_d2h));
-            HIPCHK(h, hipStreamSynchronize(h->stream_d2h));
-        }
-        return argmin_deliver(h, found, cand, capacity, ncand);
+        if (!h->stream_d2h) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
+        // (a list longer than the speculative copy is fetched on a stream of its own: the compute stream may already hold
+        //  the next batch, whose kernels this copy must not queue behind -- and they do not touch this slot's payload)
+        return argmin_deliver(h, S.cb, h->stream_d2h, cand, capacity, ncand);
     });
 }
+
+// Device-resident output (new surface, for multi-GPU jobs and device pipelines): the whole path with the candidate list
+// left ON THE DEVICE in the caller's buffer; asynchronous.  See include/pbd.h.
+int pbd_detect_batch_device_out(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels,
+                                int frame_offset, int32_t *d_payload, int capacity)
+{
+    return guarded(h, [&]() -> int {
+        if (!h || !d_frames || !d_payload) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
+        if (capacity < 0) return fail(h, PBD_ERR_INVALID, "capacity %d", capacity);
+        h->cur_depth = kDepth8U;
+        Plan *P = nullptr;
+        int rc = enqueue_detect(h, nframes, d_frames, rows, cols, channels, &P);
+        if (rc != PBD_OK) return rc;
+        if ((rc = enqueue_argmin(h, *P, nframes, P->d_scales.d, frame_offset, d_payload, capacity, h->stream)) != PBD_OK) return rc;
+        HIPCHK(h, hipGetLastError());
+        return PBD_OK;
+    });
+}
+
+int pbd_argmin_device_out(pbd_handle *h, int frame_offset, int32_t *d_payload, int capacity)
+{
+    return guarded(h, [&]() -> int {
+        if (!h || !d_payload) return PBD_ERR_INVALID;
+        (void)hipSetDevice(h->cfg.device);
+        if (h->nsubmitted != h->nwaited) return fail(h, PBD_ERR_STATE, "a submitted batch has not been waited for");
+        if (!h->cur || !h->have_dp || h->cur->kind != 0) return fail(h, PBD_ERR_STATE, "no detect result is resident on the device");
+        if (capacity < 0) return fail(h, PBD_ERR_INVALID, "capacity %d", capacity);
+        const int rc = enqueue_argmin(h, *h->cur, h->cur_frames, h->cur->d_scales.d, frame_offset, d_payload, capacity, h->stream);
+        if (rc != PBD_OK) return rc;
+        HIPCHK(h, hipGetLastError());
+        return PBD_OK;
+    });
+}
+
+void *pbd_stream(const pbd_handle *h) { return h ? reinterpret_cast<void *>(h->stream) : nullptr; }
 
 int pbd_detect_batch_device(pbd_handle *h, int nframes, const void *d_frames, int rows, int cols, int channels,
                             int32_t *cand, int capacity, int *ncand)

@@ -219,8 +219,12 @@ struct ArgminParams {
     const PartWalk *walk;         // all components concatenated
     const int *walk_off;          // [NC+1]
     int max_parts, stride, capacity;
-    int *count;                   // device counter
-    int32_t *cand;                // [capacity][stride]
+    // the candidate list as it leaves the device ("payload"): word 0 = number of roots FOUND (may exceed `capacity`), then
+    // min(found, capacity) records of `stride` words in (frame, level, component, y, x) order
+    int32_t *payload;
+    int *blk; int nblk;           // hits per block of the find kernels, then their exclusive prefix sums
+    long long ntotal;             // nframes * cell_per_frame * NC root cells
+    int frame_offset;             // added to the `frame` field of every record (frames sharded over GPUs: global frame id)
 };
 
 // ---- launchers (pbd_kernels_*.hip) ---------------------------------------------------------
@@ -243,6 +247,7 @@ void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hip
 void launch_dp_combine_seq(const DpParams &p, int nsjobs, int nframes, bool f64, hipStream_t s);
 void launch_dp_root(const DpParams &p, int nframes, bool f64, hipStream_t s);
 void launch_argmin_find(const ArgminParams &p, bool f64, hipStream_t s);
-void launch_argmin_walk(const ArgminParams &p, int ncand, bool f64, hipStream_t s);
+int argmin_find_span();       // root cells per block of the find kernels (sizes ArgminParams::blk)
+void launch_argmin_walk(const ArgminParams &p, bool f64, hipStream_t s);
 
 }  // namespace pbd

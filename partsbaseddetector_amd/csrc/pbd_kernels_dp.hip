@@ -707,53 +707,145 @@ void launch_dp_root(const DpParams &p, int nframes, bool f64, hipStream_t s)
 }
 
 // ---- argmin ------------------------------------------------------------------------------------
-// find: rootv > thresh (strict, src/DynamicProgram.cpp:208) -> append (frame, component, level, x, y, score, mix)
+// find: rootv > thresh (strict, src/DynamicProgram.cpp:208), in RASTER ORDER per (frame, level, component) as the
+// reference's Math::find (include/Math.hpp:84-93) lists them -- rootv is laid out [frame][level][component][y][x], so the
+// order (frame, level, component, y, x) the ABI promises IS the order of the element index.  Three small launches instead
+// of an atomic append + a host sort: hits per block of 1024 elements, an exclusive scan of the block counts (which also
+// leaves the TRUE number found in word 0 of the payload), then every hit writes its record header at
+// (block offset + rank inside the block).  The candidate list leaves the device already ordered, with its count in front:
+// one D2H, no host pass, and the same buffer is what a multi-GPU job hands to the collective (dist.CandidateGatherer).
+constexpr int kFindEPT = 4, kFindBlock = 256, kFindSpan = kFindEPT * kFindBlock;
+
 template <typename R>
-__global__ __launch_bounds__(256) void k_argmin_find(ArgminParams p)
+__device__ __forceinline__ int find_hits(const ArgminParams &p, long long base, bool hit[kFindEPT])
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.cell_per_frame) return;
-    const int c = blockIdx.y, frame = blockIdx.z;
-    int lo = 0, hi = p.nlevels;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (p.lv[mid].cell_off <= idx) lo = mid; else hi = mid; }
-    const LevelDesc d = p.lv[lo];
-    const int local = (int)(idx - d.cell_off);
-    const size_t HW = (size_t)d.rows * d.cols;
-    const size_t o = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NC + (size_t)c * HW + local;
-    const R v = static_cast<const R *>(p.rootv)[o];
-    if (!(v > (R)p.thresh)) return;
-    const int slot = atomicAdd(p.count, 1);
-    if (slot >= p.capacity) return;
-    int32_t *rec = p.cand + (size_t)slot * p.stride;
-    rec[0] = frame; rec[1] = c; rec[2] = lo;
-    rec[3] = local % d.cols; rec[4] = local / d.cols;
-    rec[5] = __float_as_int((float)v);   // Candidate::confidence_ is float for every T (include/Candidate.hpp:72)
-    rec[6] = 0;
-    rec[7] = p.rooti[o];   // root mixture, consumed by the walk kernel
+    const R *rv = static_cast<const R *>(p.rootv);
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < kFindEPT; ++e) {
+        const long long o = base + e;
+        hit[e] = o < p.ntotal && rv[o] > (R)p.thresh;       // NaN compares false, as in the reference's `rootv > thresh` mask
+        c += hit[e] ? 1 : 0;
+    }
+    return c;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+template <typename R>
+__global__ __launch_bounds__(kFindBlock) void k_argmin_count(ArgminParams p)
+{
+    bool hit[kFindEPT];
+    const int c = find_hits<R>(p, (long long)blockIdx.x * kFindSpan + threadIdx.x * kFindEPT, hit);
+    __shared__ int wsum[kFindBlock / 64];
+    const int lane = threadIdx.x & 63, incl = wave_incl_scan(c, lane);
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < kFindBlock / 64; ++w) t += wsum[w];
+        p.blk[blockIdx.x] = t;
+    }
+}
+
+// one workgroup: blk[b] <- sum of blk[0..b) ; payload[0] <- total
+__global__ __launch_bounds__(1024) void k_argmin_scan(ArgminParams p)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < p.nblk; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < p.nblk ? p.blk[b] : 0;
+        const int incl = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int off = carry_s;
+        for (int k = 0; k < w; ++k) off += wsum[k];
+        if (b < p.nblk) p.blk[b] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.payload[0] = carry_s;
+}
+
+template <typename R>
+__global__ __launch_bounds__(kFindBlock) void k_argmin_emit(ArgminParams p)
+{
+    bool hit[kFindEPT];
+    const long long base = (long long)blockIdx.x * kFindSpan + threadIdx.x * kFindEPT;
+    const int c = find_hits<R>(p, base, hit);
+    __shared__ int wsum[kFindBlock / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, incl = wave_incl_scan(c, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    if (c == 0) return;
+    int slot = p.blk[blockIdx.x] + incl - c;
+    for (int k = 0; k < w; ++k) slot += wsum[k];
+    const long long per_frame = p.cell_per_frame * p.NC;
+#pragma unroll
+    for (int e = 0; e < kFindEPT; ++e) {
+        if (!hit[e]) continue;
+        const int mine = slot++;
+        if (mine >= p.capacity) continue;                      // word 0 still carries the true count: the caller sees the overflow
+        const long long o = base + e;
+        const int frame = (int)(o / per_frame);
+        const long long rem = o - (long long)frame * per_frame;
+        int lo = 0, hi = p.nlevels;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (p.lv[mid].cell_off * p.NC <= rem) lo = mid; else hi = mid; }
+        const LevelDesc d = p.lv[lo];
+        const int HWi = d.rows * d.cols;
+        const int rem2 = (int)(rem - d.cell_off * p.NC);
+        const int comp = rem2 / HWi, local = rem2 - comp * HWi;
+        int32_t *rec = p.payload + 1 + (size_t)mine * p.stride;
+        rec[0] = frame; rec[1] = comp; rec[2] = lo;
+        rec[3] = local % d.cols; rec[4] = local / d.cols;
+        rec[5] = __float_as_int((float)static_cast<const R *>(p.rootv)[o]);   // Candidate::confidence_ is float for every T (include/Candidate.hpp:72)
+        rec[6] = 0;
+        rec[7] = p.rooti[o];   // root mixture, consumed by the walk kernel
+    }
 }
 
 void launch_argmin_find(const ArgminParams &p, bool f64, hipStream_t s)
-{
-    if (p.cell_per_frame == 0) return;
-    dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), p.NC, p.nframes);
-    if (f64) hipLaunchKernelGGL(k_argmin_find<double>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_argmin_find<float>, grid, dim3(256), 0, s, p);
+{   // p.nblk = ceil(p.ntotal / kFindSpan) >= 1; p.blk holds nblk ints
+    if (f64) hipLaunchKernelGGL(k_argmin_count<double>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
+    else hipLaunchKernelGGL(k_argmin_count<float>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
+    hipLaunchKernelGGL(k_argmin_scan, dim3(1), dim3(1024), 0, s, p);
+    if (f64) hipLaunchKernelGGL(k_argmin_emit<double>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
+    else hipLaunchKernelGGL(k_argmin_emit<float>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
 }
+int argmin_find_span() { return kFindSpan; }
 
 template <typename R> __device__ __forceinline__ int round_mul(int a, R s);
 // cv::Point_<int> * T -> saturate_cast<int>(a*s) = cvRound: round half to even
 template <> __device__ __forceinline__ int round_mul<float>(int a, float s) { return __float2int_rn((float)a * s); }
 template <> __device__ __forceinline__ int round_mul<double>(int a, double s) { return __double2int_rn((double)a * s); }
 
-// walk: one thread per candidate follows Ix/Iy/Ik from the root (src/DynamicProgram.cpp:218-244)
-// ncand < 0: the number of candidates is read from the device counter (pipelined entry points: the host does not
-// know it yet); the grid then strides over min(count, capacity) records
+// walk: one thread per candidate follows Ix/Iy/Ik from the root (src/DynamicProgram.cpp:218-244).  The number of
+// candidates is read from word 0 of the payload (the host never needs it to launch this); the grid strides over
+// min(found, capacity) records.  The positions and mixtures of the parts already visited sit in LDS (x | y << 16 and the
+// mixture, one column per thread: 45 KB) -- not in per-thread scratch.
+constexpr int kWalkMaxParts = 80;
 template <typename R, typename PT>
-__global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
+__global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p)
 {
-    if (ncand < 0) ncand = min(*p.count, p.capacity);
+    __shared__ int visited[kWalkMaxParts][64];
+    __shared__ uint8_t visited_m[kWalkMaxParts][64];
+    const int ncand = min(p.payload[0], p.capacity);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncand; i += gridDim.x * blockDim.x) {
-    int32_t *rec = p.cand + (size_t)i * p.stride;
+    int32_t *rec = p.payload + 1 + (size_t)i * p.stride;
     const int frame = rec[0], c = rec[1], l = rec[2];
     const LevelDesc d = p.lv[l];
     const int W = d.cols;
@@ -764,24 +856,22 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
     const size_t pbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NS;
     const size_t jbase = ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NJ;
     int32_t *rects = rec + 8;
-    // xv/yv/mv of already visited parts are kept in the record itself: x,y in the rect slots
-    // (overwritten by the final rect once all children are done is not possible in one pass), so use
-    // a small per-thread walk: parents precede children, keep coordinates in local arrays.
-    int xv[80], yv[80], mv[80];
     for (int pidx = 0; pidx < nparts; ++pidx) {
         int x, y, m;
         if (pidx == 0) {
             x = rec[3]; y = rec[4]; m = rec[7];
         } else {
             const PartWalk w = walk[pidx];
-            const int px = xv[w.parent], py = yv[w.parent], pm = mv[w.parent];
+            const int par = visited[w.parent][threadIdx.x];
+            const int px = par & 0xffff, py = par >> 16, pm = visited_m[w.parent][threadIdx.x];
             // Ix = IxRaw[k][py][px], Iy = IyRaw[k][py][Ix] with k = the winning mixture (the reference's composition)
             m = p.Ik[pbase + (size_t)(w.slot + pm) * HW + (size_t)py * W + px];
             const size_t jo = jbase + (size_t)(w.mix0 + m) * HW;
             x = static_cast<const PT *>(p.IxRaw)[jo + (size_t)px * d.rows + py];      // IxRaw is kept transposed ([x][y])
             y = static_cast<const PT *>(p.IyRaw)[jo + (size_t)py * W + x];
         }
-        xv[pidx] = x; yv[pidx] = y; mv[pidx] = m;
+        visited[pidx][threadIdx.x] = x | (y << 16);
+        visited_m[pidx][threadIdx.x] = (uint8_t)m;
         const int ks = walk[pidx].ksize[m];
         const int x1 = round_mul<R>(x - 1, scale), y1 = round_mul<R>(y - 1, scale);
         const int x2 = x1 + round_mul<R>(ks, scale) - 1, y2 = y1 + round_mul<R>(ks, scale) - 1;
@@ -791,21 +881,21 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p, int ncand)
         rects[pidx * 4 + 2] = max(x1, x2) - rx;
         rects[pidx * 4 + 3] = max(y1, y2) - ry;
     }
+    rec[0] = frame + p.frame_offset;   // index within the batch -> global frame id of a sharded job (0 on one GPU)
     rec[6] = nparts;
     rec[7] = 0;
     }
 }
 
-void launch_argmin_walk(const ArgminParams &p, int ncand, bool f64, hipStream_t s)
+void launch_argmin_walk(const ArgminParams &p, bool f64, hipStream_t s)
 {
-    if (ncand == 0) return;
-    const int blocks = ncand < 0 ? std::min((p.capacity + 63) / 64, 4096) : (ncand + 63) / 64;
+    const int blocks = std::min((p.capacity + 63) / 64, 2048);
     if (p.ptr8) {
-        if (f64) hipLaunchKernelGGL((k_argmin_walk<double, uint8_t>), dim3(blocks), dim3(64), 0, s, p, ncand);
-        else hipLaunchKernelGGL((k_argmin_walk<float, uint8_t>), dim3(blocks), dim3(64), 0, s, p, ncand);
+        if (f64) hipLaunchKernelGGL((k_argmin_walk<double, uint8_t>), dim3(blocks), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((k_argmin_walk<float, uint8_t>), dim3(blocks), dim3(64), 0, s, p);
     } else {
-        if (f64) hipLaunchKernelGGL((k_argmin_walk<double, int16_t>), dim3(blocks), dim3(64), 0, s, p, ncand);
-        else hipLaunchKernelGGL((k_argmin_walk<float, int16_t>), dim3(blocks), dim3(64), 0, s, p, ncand);
+        if (f64) hipLaunchKernelGGL((k_argmin_walk<double, int16_t>), dim3(blocks), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((k_argmin_walk<float, int16_t>), dim3(blocks), dim3(64), 0, s, p);
     }
 }
 

@@ -113,6 +113,10 @@ class Handle:
             raise PbdError(rc, self.lib.pbd_last_error(self.h).decode())
         return rc
 
+    def stream_ptr(self) -> int:
+        """pbd_stream: the hipStream_t the handle's kernels run on (wrap it with torch.cuda.ExternalStream to order torch work behind it)"""
+        return int(self.lib.pbd_stream(self.h) or 0)
+
     def set_level_shard(self, rank: int, world: int) -> None:
         """pbd_set_level_shard: this handle computes only its share of the pyramid levels of each frame"""
         self.check(self.lib.pbd_set_level_shard(self.h, rank, world))
@@ -353,6 +357,24 @@ class PartsBasedDetector:
         if raw:
             return self._buf, n.value
         return self.hd.unpack_candidates(self._buf, n.value)
+
+    def submit_batch_device(self, d_frames_ptr: int, nframes: int, rows: int, cols: int, cn: int) -> None:
+        """pbd_detect_batch_device_submit: like submit_batch for frames already resident in device memory"""
+        self._need()
+        self.hd.check(self.hd.lib.pbd_detect_batch_device_submit(self.hd.h, nframes, d_frames_ptr, rows, cols, cn))
+
+    def detect_batch_device_out(self, d_frames_ptr: int, nframes: int, rows: int, cols: int, cn: int, frame_offset: int,
+                                d_payload_ptr: int, capacity: int) -> None:
+        """pbd_detect_batch_device_out: the whole path, candidate list left on the device in int32[1 + capacity*stride]
+        ([found | sorted records], frame ids + frame_offset); asynchronous on the handle's stream"""
+        self._need()
+        self.hd.check(self.hd.lib.pbd_detect_batch_device_out(self.hd.h, nframes, d_frames_ptr, rows, cols, cn, frame_offset,
+                                                              d_payload_ptr, capacity))
+
+    def argmin_device_out(self, frame_offset: int, d_payload_ptr: int, capacity: int) -> None:
+        """pbd_argmin_device_out: re-emit the candidate list of the batch still resident on the device (after an overflow)"""
+        self._need()
+        self.hd.check(self.hd.lib.pbd_argmin_device_out(self.hd.h, frame_offset, d_payload_ptr, capacity))
 
     def detect_batch_device(self, d_frames_ptr: int, nframes: int, rows: int, cols: int, cn: int,
                             capacity: Optional[int] = None, raw: bool = False):

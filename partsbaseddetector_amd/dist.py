@@ -60,27 +60,46 @@ def _grown(need: int) -> int:
     return cap
 
 
+class RankFailed(RuntimeError):
+    """raised on EVERY rank, after the collective, when some rank's detect step failed (its payload carries a negative count)"""
+
+
 class CandidateGatherer:
-    """The per-batch gather with its buffers allocated once: a pinned host staging buffer for the payload, one
-    device tensor for the send side and one [world, payload] tensor for the receive side (a single
-    ``all_gather_into_tensor``).  ``root_only`` lets the other ranks skip the copy back and the unpacking of the
-    records (every rank still takes part in the collective and reads the `world` counts, which is what keeps the
-    grow-on-overflow decision identical on all ranks).
+    """The per-batch gather with its buffers allocated once: one [world, payload] device tensor for the receive side (a
+    single ``all_gather_into_tensor``), two payload tensors for the send side and pinned host mirrors.  Two ways in:
 
-    ``cap`` is the initial capacity in records; size it from the detector's ``max_candidates`` when memory allows
-    -- a too-small value costs one extra collective the first time it overflows, never an error."""
+    * ``begin_device()``: the payload was written ON THE DEVICE by ``pbd_detect_batch_device_out`` straight into
+      ``self.payload`` (count in word 0, records sorted, global frame ids) -- nothing passes through the host before the
+      collective, and afterwards only ``world`` counts (every rank) and the records (rank 0) come back.  This is the
+      multi-GPU path.
+    * ``begin(buf, n, frame_offset)``: host records (gloo tests, level sharding): packed into a pinned buffer, copied up.
 
-    def __init__(self, stride: int, cap: int, device):
+    ``root_only`` lets the other ranks skip the copy back and the unpacking of the records (every rank still takes part
+    in the collective and reads the `world` counts, which is what keeps the grow-on-overflow decision identical on all
+    ranks).  ``force_collective`` issues the collective at world size 1 as well: the one-GPU rehearsal of the RCCL path.
+
+    ``cap`` is the initial capacity in records of what the COLLECTIVE moves per rank; a too-small value costs one extra
+    collective the first time it overflows, never an error.  ``cap_full`` (device path) is the size of the payload tensors
+    the kernels write into -- the detector's ``max_candidates``: the collective sends a prefix of that tensor, so after
+    an overflow the same, still intact, tensor is simply sent again with a longer prefix (the detector may already be
+    working on the next batch: nothing has to be recomputed).  Only a list longer than ``cap_full`` is an error
+    (OverflowError on every rank, like PBD_ERR_CAPACITY on one GPU)."""
+
+    def __init__(self, stride: int, cap: int, device, force_collective: bool = False, cap_full: int = 0):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.stride, self.device = stride, torch.device(device)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.collectives = 0          # all_gather calls issued so far (tests / bench: 1 per step in steady state)
         self.grown = 0                # how often the buffers had to grow
         self._copy_done = None        # event after the last H2D copy out of host_send (cuda only)
-        self._pending = None          # (work handle, true count, records beyond the capacity) between begin() and finish()
+        self._pending = None          # state between begin*() and finish()
+        self.cap_full = max(int(cap_full), int(cap), 1)
+        self.dev_send = None
+        self._cur = 0
         self._alloc(max(int(cap), 1))
 
     def _alloc(self, cap: int):
@@ -90,8 +109,19 @@ class CandidateGatherer:
         pin = self.device.type == "cuda"
         self.host_send = torch.zeros(self.n, dtype=torch.int32, pin_memory=pin)
         self.host_recv = torch.zeros(self.world * self.n, dtype=torch.int32, pin_memory=pin)
-        self.dev_send = torch.zeros(self.n, dtype=torch.int32, device=self.device)
         self.dev_recv = torch.zeros(self.world * self.n, dtype=torch.int32, device=self.device)
+        # two send buffers of the FULL size: the collective of batch k may still read one while batch k+1's kernels fill
+        # the other; a buffer is reused only after the finish() of the batch that used it.  They survive a growth of the
+        # collective's capacity (the overflowed list is in one of them) unless the host path outgrows them.
+        if self.dev_send is None or cap > self.cap_full:
+            self.cap_full = max(self.cap_full, cap)
+            self.dev_send = [torch.zeros(1 + self.cap_full * self.stride, dtype=torch.int32, device=self.device) for _ in range(2)]
+
+    @property
+    def payload(self):
+        """the device tensor int32[1 + cap_full*stride] the NEXT batch's candidate list is to be written into
+        (``pbd_detect_batch_device_out(..., payload.data_ptr(), cap_full)``) before ``begin_device()``"""
+        return self.dev_send[self._cur]
 
     def _wait_host_send_free(self):
         # the previous step's asynchronous copy out of the pinned buffer must have finished before it is rewritten
@@ -99,17 +129,41 @@ class CandidateGatherer:
             self._copy_done.synchronize()
             self._copy_done = None
 
+    def _issue(self, send):
+        work = None
+        if self.collective:
+            work = self.dist.all_gather_into_tensor(self.dev_recv, send[: self.n], async_op=True)   # a prefix: contiguous
+            self.collectives += 1
+        return work
+
     # ---- the gather in two halves, so that a caller can put the next batch's compute between them -------------------
-    # begin(): pack + H2D + the collective, issued asynchronously (`async_op=True`: RCCL runs it on its own stream next
-    # to the detection kernels, gloo on its worker threads); finish(): read the counts, grow-and-repeat on overflow,
-    # copy the records out.  One collective per batch, every rank issues them in the same order, and a finish() always
-    # precedes the next begin(), so the buffers are never rewritten under a collective in flight.
+    # begin*(): the collective, issued asynchronously (`async_op=True`: RCCL runs it on its own stream next to the
+    # detection kernels, gloo on its worker threads); finish(): read the counts, grow-and-repeat on overflow, copy the
+    # records out.  One collective per batch, every rank issues them in the same order, and a finish() always precedes
+    # the next begin*(), so the buffers are never rewritten under a collective in flight.
+    def begin_device(self, producer_stream=None):
+        """`self.payload` is being filled by kernels enqueued on `producer_stream` (a torch stream, e.g.
+        ``torch.cuda.ExternalStream(pbd_stream(h))``; None: torch's current stream).  Nothing is copied: the collective is
+        ordered behind those kernels and reads the tensor where it is."""
+        if self._pending is not None:
+            raise RuntimeError("CandidateGatherer.begin_device(): the previous gather was not finished")
+        torch = self.torch
+        send = self.dev_send[self._cur]
+        self._cur ^= 1
+        if self.device.type == "cuda" and producer_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(producer_stream)
+            torch.cuda.current_stream(self.device).wait_event(ev)      # the collective (and finish()'s reads) wait for the kernels
+        self._pending = ("dev", self._issue(send), send, None, None)
+
     def begin(self, buf: np.ndarray, n: int, frame_offset: int):
+        """host records.  n < 0 flags a failed detect step on this rank: the rank still enters the collective and every rank
+        raises RankFailed from finish()."""
         if self._pending is not None:
             raise RuntimeError("CandidateGatherer.begin(): the previous gather was not finished")
         n, stride = int(n), self.stride
         self._wait_host_send_free()
-        m = min(n, self.cap)
+        m = min(max(n, 0), self.cap)
         hs = self.host_send.numpy()
         hs[0] = n                                         # the TRUE count, also when it does not fit
         if m:
@@ -121,16 +175,17 @@ class CandidateGatherer:
         if n > m:
             spill = np.array(buf[m * stride: n * stride], np.int32).reshape(n - m, stride)
             spill[:, 0] += frame_offset
+        send = self.dev_send[self._cur]
+        self._cur ^= 1
         work = None
-        if self.world > 1:
+        if self.collective:
             # only the used prefix crosses PCIe; the collective moves the fixed-size payload
-            self.dev_send[: 1 + m * stride].copy_(self.host_send[: 1 + m * stride], non_blocking=True)
+            send[: 1 + m * stride].copy_(self.host_send[: 1 + m * stride], non_blocking=True)
             if self.device.type == "cuda":
                 self._copy_done = self.torch.cuda.Event()
                 self._copy_done.record(self.torch.cuda.current_stream(self.device))
-            work = self.dist.all_gather_into_tensor(self.dev_recv, self.dev_send, async_op=True)
-            self.collectives += 1
-        self._pending = (work, n, spill)
+            work = self._issue(send)
+        self._pending = ("host", work, send, n, spill)
 
     @property
     def pending(self) -> bool:
@@ -139,30 +194,44 @@ class CandidateGatherer:
     def finish(self, root_only: bool = False):
         if self._pending is None:
             raise RuntimeError("CandidateGatherer.finish(): no gather in flight")
-        work, n, spill = self._pending
+        kind, work, send, n, spill = self._pending
         self._pending = None
         stride = self.stride
-        hs = self.host_send.numpy()
-        if self.world == 1:
-            counts = np.array([n])
-        else:
+        if work is not None:
             work.wait()
             counts = self.dev_recv[:: self.n].cpu().numpy()          # world ints, read by EVERY rank
+        elif kind == "dev":
+            counts = send[:1].cpu().numpy()
+        else:
+            counts = np.array([n])
+        if int(counts.min()) < 0:
+            raise RankFailed(f"detect failed on rank(s) {[r for r, c in enumerate(counts) if c < 0]}")
         need = int(counts.max())
         if need > self.cap:
             # some rank did not fit: every rank sees that, grows to the same capacity and repeats the collective with its
-            # own records (global frame ids already applied) -- synchronously, this is the rare path
+            # own records -- synchronously, this is the rare path
+            if kind == "dev" and need > self.cap_full:
+                raise OverflowError(f"{need} candidates on some rank, payload tensors hold {self.cap_full}: raise max_candidates")
+            self.grown += 1
+            if kind == "dev":
+                # the overflowed list is complete in `send` (sized cap_full, not rewritten before this finish()): send a longer prefix
+                self._alloc(min(_grown(need), self.cap_full))
+                self._pending = ("dev", self._issue(send), send, None, None)
+                return self.finish(root_only)
+            hs = self.host_send.numpy()
             m = min(n, self.cap)
             mine = hs[1:1 + m * stride].reshape(m, stride).copy()
             if spill is not None:
                 mine = np.concatenate([mine, spill], axis=0)
             self._wait_host_send_free()
             self._alloc(_grown(need))
-            self.grown += 1
             self.begin(mine.ravel(), n, 0)
             return self.finish(root_only)
-        if self.world == 1:
-            return hs[1:1 + n * stride].reshape(n, stride).copy()
+        if work is None:
+            if kind == "dev":
+                k = int(counts[0])
+                return send[1:1 + k * stride].cpu().numpy().reshape(k, stride)
+            return self.host_send.numpy()[1:1 + n * stride].reshape(n, stride).copy()
         if root_only and self.rank != 0:
             return None
         parts = []
@@ -189,14 +258,56 @@ def gather_candidates(buf: np.ndarray, n: int, stride: int, cap: int, frame_offs
     return CandidateGatherer(stride, cap, device).gather(buf, n, frame_offset)
 
 
+class DeviceBatchGather:
+    """Frames sharded over the ranks, candidate lists gathered without a host round trip: glue between a
+    ``detector.PartsBasedDetector`` and a ``CandidateGatherer`` on a cuda device.
+
+        g = DeviceBatchGather(det, CandidateGatherer(stride, cap, "cuda:0", cap_full=det.hd.max_candidates))
+        for every batch k:
+            records_of_k_minus_1 = g.submit(d_frames_ptr, nframes, rows, cols, cn, frame_offset, root_only=True)
+        records_of_last = g.collect(root_only=True)
+
+    ``submit`` enqueues the whole path of batch k (the candidate list goes into this batch's payload tensor, on the
+    device), THEN finishes the gather of batch k-1 -- whose collective ran under batch k-1's successor being enqueued and is
+    long complete -- and issues batch k's collective behind its kernels.  The detection kernels run on the detector's own
+    stream; the collective is ordered behind them with an event."""
+
+    def __init__(self, det, gatherer: CandidateGatherer):
+        import torch
+        self.det, self.g = det, gatherer
+        self.stream = torch.cuda.ExternalStream(det.hd.stream_ptr(), device=gatherer.device)
+
+    def submit(self, d_frames_ptr: int, nframes: int, rows: int, cols: int, cn: int, frame_offset: int, root_only: bool = False):
+        pay = self.g.payload                     # not the tensor a pending gather is reading: the buffers alternate
+        self.det.detect_batch_device_out(d_frames_ptr, nframes, rows, cols, cn, frame_offset, pay.data_ptr(), self.g.cap_full)
+        prev = self.g.finish(root_only) if self.g.pending else None
+        self.g.begin_device(self.stream)
+        return prev
+
+    def collect(self, root_only: bool = False):
+        return self.g.finish(root_only) if self.g.pending else None
+
+
 def detect_level_sharded(det, im, gatherer: "CandidateGatherer", root_only: bool = False):
     """ONE frame over all ranks (secondary partitioning): every rank holds the frame, computes its
     share of the pyramid levels (`pbd_set_level_shard`: longest-processing-time assignment over the level sizes) and the
     candidate lists are gathered with the usual single collective; the records come back sorted by
-    (frame, level, component, y, x) like a single-GPU call."""
-    det.hd.set_level_shard(gatherer.rank, gatherer.world)
-    cands = det.detect(im)
+    (frame, level, component, y, x) like a single-GPU call.
+
+    The shard is handle state: it is restored to (0, 1) before this returns, so a later detect() / detect_batch() on the
+    same detector sees every level again.  A rank whose share fails (e.g. PBD_ERR_CAPACITY -- every rank owns different
+    levels, so only one may fail) still enters the collective, flagged, and ALL ranks raise RankFailed afterwards: nobody
+    is left blocked in the all_gather."""
+    from ._lib import PbdError
     stride = det.hd.stride
+    cands, err = [], None
+    det.hd.set_level_shard(gatherer.rank, gatherer.world)
+    try:
+        cands = det.detect(im)
+    except PbdError as e:
+        err = e
+    finally:
+        det.hd.set_level_shard(0, 1)
     buf = np.zeros(max(len(cands), 1) * stride, np.int32)
     for i, c in enumerate(cands):
         r = buf[i * stride:(i + 1) * stride]
@@ -204,7 +315,10 @@ def detect_level_sharded(det, im, gatherer: "CandidateGatherer", root_only: bool
         r[5:6] = np.float32(c.score()).view(np.int32)
         r[6] = len(c.parts)
         r[8:8 + 4 * len(c.parts)] = c.parts.ravel()
-    rec = gatherer.gather(buf, len(cands), frame_offset=0, root_only=root_only)
+    try:
+        rec = gatherer.gather(buf, -1 if err is not None else len(cands), frame_offset=0, root_only=root_only)
+    except RankFailed as rf:
+        raise RankFailed(f"{rf}; this rank: {err}") from err
     if rec is None:
         return None
     order = np.lexsort((rec[:, 3], rec[:, 4], rec[:, 1], rec[:, 2], rec[:, 0]))

@@ -250,3 +250,118 @@ def test_gatherer_begin_finish_pipelined_with_overflow():
         assert np.array_equal(rec[:, 0], want_frame)
         assert np.array_equal(rec[:, 1], np.concatenate([np.arange(c[0]), np.arange(c[1])]))
         assert np.array_equal(rec[:, 2], np.concatenate([np.full(c[0], 1000 * step), np.full(c[1], 1000 * step + 100)]))
+
+
+def _device_path_worker(rank, world, port, q):
+    """the device-resident path of the gatherer (what bench.py uses for N > 1), rehearsed with CPU tensors: the "kernels"
+    are numpy writes into g.payload (a tensor of the FULL capacity, of which the collective sends a prefix)"""
+    import torch.distributed as dist
+    from partsbaseddetector_amd import dist as pd
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        stride = 12
+        g = pd.CandidateGatherer(stride, cap=16, device="cpu", cap_full=64)
+        counts = [(3, 5), (7, 2), (4, 40), (6, 6), (0, 1)]
+
+        def emit(payload, cap, step):
+            n = counts[step][rank]
+            p = payload.numpy()
+            p[0] = n                                          # the TRUE count, also when it does not fit
+            m = min(n, cap)
+            rec = p[1:1 + m * stride].reshape(m, stride)
+            rec[:] = 1000 * step + 100 * rank
+            rec[:, 0] = np.arange(m) + 50 * rank              # global frame ids, written by the "walk kernel"
+            rec[:, 1] = np.arange(m)
+
+        out, payloads = [], []
+        for step in range(len(counts)):
+            # the order of dist.DeviceBatchGather.submit: the "kernels" of batch k fill this batch's payload tensor first,
+            # then the gather of batch k-1 is finished (an overflow is repaired from ITS tensor, which is still intact)
+            payloads.append(g.payload.data_ptr())
+            emit(g.payload, g.cap_full, step)
+            if g.pending:
+                out.append(g.finish(root_only=True))
+            g.begin_device(None)
+        out.append(g.finish(root_only=True))
+        try:                                                   # a list longer than the payload tensors: every rank raises
+            emit(g.payload, g.cap_full, 2)
+            g.payload.numpy()[0] = 1000
+            g.begin_device(None)
+            g.finish()
+            too_long = "no error"
+        except OverflowError as e:
+            too_long = str(e)
+        q.put((rank, out, g.collectives, g.grown, payloads[0] != payloads[1], too_long))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gatherer_device_path_pipelined_with_overflow():
+    """begin_device(): no host packing at all -- a prefix of the payload tensor is handed to the collective as it is;
+    consecutive batches use alternating payload tensors; an overflow makes every rank grow and send a longer prefix of the
+    same tensor (nothing is recomputed, the next batch may already be in flight)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_device_path_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, ncoll, grown, alternates, too_long = q.get(timeout=180)
+        res[rank] = (out, ncoll, grown, alternates)
+        assert "raise max_candidates" in too_long
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    stride = 12
+    counts = [(3, 5), (7, 2), (4, 40), (6, 6), (0, 1)]
+    assert res[0][1] == res[1][1] == 7 and res[0][2] == res[1][2] == 1      # 5 steps + one repeat + the too-long list; grown once
+    assert res[0][3] and res[1][3]
+    assert all(o is None for o in res[1][0])
+    for step, c in enumerate(counts):
+        rec = res[0][0][step]
+        assert rec.shape == (sum(c), stride)
+        assert np.array_equal(rec[:, 0], np.concatenate([np.arange(c[0]), np.arange(c[1]) + 50]))
+        assert np.array_equal(rec[:, 1], np.concatenate([np.arange(c[0]), np.arange(c[1])]))
+        assert np.array_equal(rec[:, 2], np.concatenate([np.full(c[0], 1000 * step), np.full(c[1], 1000 * step + 100)]))
+
+
+def _rank_failed_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from partsbaseddetector_amd import dist as pd
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        stride = 12
+        g = pd.CandidateGatherer(stride, cap=16, device="cpu")
+        buf = np.zeros(4 * stride, np.int32)
+        try:
+            g.gather(buf, -1 if rank == 1 else 4, frame_offset=0)          # rank 1's detect step failed
+            q.put((rank, "no error"))
+        except pd.RankFailed as e:
+            q.put((rank, str(e)))
+        # the group is still usable: nobody is stuck inside the collective
+        rec = g.gather(buf, 2, frame_offset=0)
+        q.put((rank, rec.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failed_rank_does_not_block_the_others():
+    """a rank whose detect raised used to skip the collective and leave the others blocked in all_gather.  Now
+    it enters with a negative count and every rank raises RankFailed after the collective."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_failed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    msgs = {r: m for r, m in got if isinstance(m, str)}
+    assert set(msgs) == {0, 1} and all("rank(s) [1]" in m for m in msgs.values())
+    assert sorted(m for r, m in got if not isinstance(m, str)) == [(4, 12), (4, 12)]

@@ -1,0 +1,207 @@
+"""Device-resident candidate lists and the RCCL branch of the gather, on ONE GPU.
+
+* pbd_detect_batch_device_out / pbd_argmin_device_out / pbd_detect_batch_device_submit against pbd_detect_batch (which the
+  full-size tests pin to the oracle): same records, same (frame, level, component, y, x) order -- now produced on the device.
+* torch.distributed backend "nccl" (= RCCL), world size 1, in a fresh child process: dist.CandidateGatherer(device="cuda")
+  with the collective really issued, driven through begin_device() / finish() by dist.DeviceBatchGather one batch behind
+  the detector, one overflow-grow cycle repaired while the next batch is in flight, the host-record path, and detect_level_sharded followed by a full detect (the shard is restored).
+  No scaling claim can come from one GPU; this executes every line of the cuda branch before the driver's 8-GPU run does.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from partsbaseddetector_amd import synth
+from partsbaseddetector_amd import model as M
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _records(det, frames):
+    n_buf = det.detect_batch(frames)
+    st = det.hd.stride
+    rec = np.zeros((len(n_buf), st), np.int32)
+    for i, c in enumerate(n_buf):
+        rec[i, :5] = (c.frame, c.component, c.level, c.root[0], c.root[1])
+        rec[i, 5:6] = np.float32(c.score()).view(np.int32)
+        rec[i, 6] = len(c.parts)
+        rec[i, 8:8 + 4 * len(c.parts)] = c.parts.ravel()
+    return rec
+
+
+def test_device_out_payload_equals_host_records(oracle):
+    import torch
+    from partsbaseddetector_amd import detector
+    model = M.synthetic_tiny_model(thresh=0.5)
+    det = detector.PartsBasedDetector(device=0, max_batch=4)
+    det.distributeModel(model)
+    frames = [synth.synthetic_frame(40 + i, 120, 150, 3) for i in range(4)]
+    want = _records(det, frames)
+    assert len(want) > 8
+    # sorted by (frame, level, component, y, x): the order the ABI promises, now produced on the device
+    keys = [tuple(r[[0, 2, 1, 4, 3]]) for r in want]
+    assert keys == sorted(keys)
+    st = det.hd.stride
+    d_frames = torch.from_numpy(np.stack(frames)).cuda()
+    cap = 256
+    pay = torch.full((1 + cap * st,), -7, dtype=torch.int32, device="cuda")
+    det.detect_batch_device_out(d_frames.data_ptr(), 4, 120, 150, 3, 1000, pay.data_ptr(), cap)
+    det.hd.check(det.hd.lib.pbd_synchronize(det.hd.h))
+    got = pay.cpu().numpy()
+    assert got[0] == len(want)
+    rec = got[1:1 + len(want) * st].reshape(len(want), st)
+    shifted = want.copy()
+    shifted[:, 0] += 1000                                   # global frame ids written by the walk kernel
+    assert np.array_equal(rec, shifted)
+    assert np.all(got[1 + len(want) * st:] == -7)           # nothing written past the list
+    # a payload that is too small: word 0 still carries the TRUE count, the first `cap` records of the order are present
+    small = 5
+    pay2 = torch.full((1 + small * st + 3,), -7, dtype=torch.int32, device="cuda")
+    det.argmin_device_out(0, pay2.data_ptr(), small)         # re-emit from the resident DP result: no second detect
+    det.hd.check(det.hd.lib.pbd_synchronize(det.hd.h))
+    got2 = pay2.cpu().numpy()
+    assert got2[0] == len(want) and np.array_equal(got2[1:1 + small * st].reshape(small, st), want[:small])
+    assert np.all(got2[1 + small * st:] == -7)
+    # capacity 0: only the count
+    pay3 = torch.full((4,), -7, dtype=torch.int32, device="cuda")
+    det.argmin_device_out(0, pay3.data_ptr(), 0)
+    det.hd.check(det.hd.lib.pbd_synchronize(det.hd.h))
+    assert pay3.cpu().numpy().tolist() == [len(want), -7, -7, -7]
+    # the host entry point truncates the same way: the FIRST `capacity` records, with PBD_ERR_CAPACITY
+    from partsbaseddetector_amd._lib import PbdError
+    import ctypes as C
+    buf, n = np.zeros(small * st, np.int32), C.c_int()
+    rc = det.hd.lib.pbd_detect_batch_device(det.hd.h, 4, d_frames.data_ptr(), 120, 150, 3, buf.ctypes.data, small, C.byref(n))
+    assert rc == -4 and n.value == small and np.array_equal(buf.reshape(small, st), want[:small])
+    # one frame of it against the oracle, through the device payload
+    w = oracle.detect(model.flatten(), frames[2])
+    mine = rec[rec[:, 0] == 1002]
+    assert len(mine) == len(w)
+    for r, ww in zip(mine, w):
+        assert (r[2], r[1], r[4], r[3]) == (ww["level"], ww["component"], ww["root_y"], ww["root_x"])
+        assert np.array_equal(r[8:8 + 4 * r[6]].reshape(-1, 4), ww["parts"])
+    det.hd.close()
+
+
+def test_device_submit_wait_pipelined():
+    """pbd_detect_batch_device_submit: two batches of device-resident frames in flight; a batch with more candidates than
+    the speculative read-back covered is fetched completely (the guess starts at 1024 records and follows the last batch)"""
+    import torch
+    from partsbaseddetector_amd import detector
+    model = M.synthetic_tiny_model(thresh=-0.2)               # a low threshold: thousands of candidates per batch
+    det = detector.PartsBasedDetector(device=0, max_batch=3, max_candidates=1 << 16)
+    det.distributeModel(model)
+    batches = [[synth.synthetic_frame(7 * b + i, 96, 128, 3) for i in range(3 if b != 1 else 1)] for b in range(4)]
+    want = [_records(det, fr) for fr in batches]
+    assert max(len(w) for w in want) > 1024 > 0 and min(len(w) for w in want) > 0
+    dev = [torch.from_numpy(np.stack(fr)).cuda() for fr in batches]
+    got = []
+    det.submit_batch_device(dev[0].data_ptr(), len(batches[0]), 96, 128, 3)
+    for b in range(1, 4):
+        det.submit_batch_device(dev[b].data_ptr(), len(batches[b]), 96, 128, 3)
+        buf, n = det.wait_batch(raw=True)
+        got.append(np.array(buf[: n * det.hd.stride]).reshape(n, det.hd.stride))
+    buf, n = det.wait_batch(raw=True)
+    got.append(np.array(buf[: n * det.hd.stride]).reshape(n, det.hd.stride))
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    det.hd.close()
+
+
+_CHILD = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, {root!r})
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = str({port})
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from partsbaseddetector_amd import dist as pd, synth, detector
+from partsbaseddetector_amd import model as M
+
+res = {{"backend": dist.get_backend(), "world": dist.get_world_size()}}
+model = M.synthetic_tiny_model(thresh=0.3)
+det = detector.PartsBasedDetector(device=0, max_batch=4, max_candidates=1 << 16)
+det.distributeModel(model)
+st = det.hd.stride
+batches = [[synth.synthetic_frame(11 * b + i + 1, 120, 150, 3) for i in range(4)] for b in range(3)]
+want = []
+for fr in batches:
+    buf = np.zeros((1 << 16) * st, np.int32)
+    cands = det.detect_batch(fr)
+    want.append([(c.frame, c.component, c.level, c.root[0], c.root[1], c.score(), c.parts.tobytes()) for c in cands])
+dev = [torch.from_numpy(np.stack(fr)).cuda() for fr in batches]
+
+def norm(rec, off):
+    return [(int(r[0]) - off, int(r[1]), int(r[2]), int(r[3]), int(r[4]), float(r[5:6].view(np.float32)[0]),
+             r[8:8 + 4 * int(r[6])].astype(np.int32).tobytes()) for r in rec]
+
+# ---- device path: payload written by the kernels, all_gather_into_tensor straight from a prefix of it ----
+g = pd.CandidateGatherer(st, cap=4, device="cuda:0", force_collective=True, cap_full=det.hd.max_candidates)   # cap 4: the first batch overflows
+assert g.collective
+dg = pd.DeviceBatchGather(det, g)
+outs = []
+for b in range(3):
+    prev = dg.submit(dev[b].data_ptr(), 4, 120, 150, 3, frame_offset=100 * b, root_only=True)   # batch b enqueued, THEN batch b-1 collected
+    if b > 0:
+        outs.append(prev)
+    else:
+        assert prev is None
+outs.append(dg.collect(root_only=True))
+assert dg.collect() is None
+res["device_ok"] = all(norm(o, 100 * b) == w for b, (o, w) in enumerate(zip(outs, want)))
+res["grown"] = g.grown
+res["collectives"] = g.collectives
+res["cap_after"] = g.cap
+res["counts"] = [len(w) for w in want]
+
+# ---- host-record path on cuda (pinned staging, H2D, collective, D2H) incl. overflow ----
+g3 = pd.CandidateGatherer(st, cap=2, device="cuda:0", force_collective=True)
+buf = np.zeros((1 << 12) * st, np.int32)
+cands = det.detect_batch(batches[1])
+raw, n = det.detect_batch_device(dev[1].data_ptr(), 4, 120, 150, 3, raw=True)
+rec = g3.gather(np.array(raw[: n * st]), n, frame_offset=7)
+res["host_ok"] = norm(rec, 7) == want[1] and g3.grown == 1
+
+# ---- one frame over the "ranks" of this world (1): the shard must be restored afterwards ----
+g4 = pd.CandidateGatherer(st, cap=64, device="cuda:0", force_collective=True)
+im = batches[2][1]
+one = det.detect(im)
+rec = pd.detect_level_sharded(det, im, g4)
+res["level_ok"] = norm(rec, 0) == [(c.frame, c.component, c.level, c.root[0], c.root[1], c.score(), c.parts.tobytes()) for c in one]
+again = det.detect_batch(batches[2])
+res["restored"] = [(c.frame, c.component, c.level, c.root[0], c.root[1], c.score(), c.parts.tobytes()) for c in again] == want[2]
+det.hd.close()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+'''
+
+
+def test_rccl_world1_device_gather(tmp_path):
+    """fresh child process: torch.distributed 'nccl' at world size 1 with the collective issued (force_collective)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD.format(root=ROOT, port=port))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    res = json.loads(line[7:])
+    assert res["backend"] == "nccl" and res["world"] == 1
+    assert res["device_ok"], res
+    assert res["grown"] == 1 and res["cap_after"] >= max(res["counts"]), res      # cap 4 -> grown once to fit every batch
+    assert res["collectives"] == 4, res                                            # 3 batches + one repeat (found while batch 1 was already enqueued)
+    assert res["host_ok"] and res["level_ok"] and res["restored"], res
