@@ -17,6 +17,13 @@ MAX_LEVELS = 128
 
 
 def build(force: bool = False) -> str:
+    # PBD_ORACLE_SO: another build of the same sources (the sanitised one, a -O3 one) -- tests/test_oracle_sanitized.py and
+    # bench.py's cpu_baseline use it; the file must already exist
+    alt = os.environ.get("PBD_ORACLE_SO")
+    if alt:
+        if not os.path.exists(alt):
+            raise FileNotFoundError(alt)
+        return alt
     so = os.path.join(_HERE, "libpbd_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("pbd_oracle.c", "pbd_oracle_impl.inc", "pbd_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

@@ -56,6 +56,35 @@ __device__ __forceinline__ R quad_val(double a, double b, int x, R y)
     if (BZ) return (R)(a * (double)__mul24(x, x) + (double)y);
     return (R)((a * (double)__mul24(x, x) + b * (double)x) + (double)y);     // |x| < 2^16
 }
+// The pop decision `s <= z[k]` of the envelope scan (DistanceTransform.hpp:162) WITHOUT the double-precision intersection,
+// whenever single precision can already tell: s32 is the same quotient evaluated in fp32 and M bounds |s32 - s| for the
+// exactly rounded s the reference computes --
+//   numerator (y1 - y0) [- b*d] + a*sq: every fp32 operation is correctly rounded, so its error is at most
+//   2^-23 (|y1 - y0| + |b*d| + |a*sq|); denominator 2a*d, v_rcp_f32 (1 ulp) and the product add 2^-22 relative; the
+//   reference's own rounding of s to float adds 2^-24: |s32 - s| <= 3.5 * 2^-23 * X with X = (|dy| + |b d| + |a sq|) / |2 a d|.
+// M = 2^-20 * X leaves a factor 2.3 on top.  Returns +1 (s <= z for certain), -1 (s > z for certain) or 0 (undecided: within
+// M of z, or anything non-finite -- every comparison with a NaN is false): the caller then evaluates the reference's
+// expression, so the decision taken is ALWAYS the reference's.  The wave runs 2.45 pop iterations per element of which a lane
+// needs 0.71 (tools/dt_stats.sh); each used to pay a full fp64 divide.  Only for T = float (the inputs are then exact in fp32).
+template <bool BZ>
+__device__ __forceinline__ int quad_pop_test(float a, float b, int x0, int x1, float y0, float y1, float z)
+{
+    const int dx = x1 - x0;
+    const float dd = (float)dx;
+    const float sq = (float)(int)__umul24((unsigned)dx, (unsigned)(x1 + x0));     // < 2^24: exact
+    const float dy = y1 - y0;
+    const float t = a * sq;
+    float num, mag;
+    if (BZ) { num = dy + t; mag = fabsf(dy) + fabsf(t); }
+    else { const float u = b * dd; num = (dy - u) + t; mag = (fabsf(dy) + fabsf(u)) + fabsf(t); }
+    const float r = __builtin_amdgcn_rcpf((2.0f * a) * dd);
+    const float s32 = num * r;
+    const float M = (mag * fabsf(r)) * 9.5367431640625e-07f;     // 2^-20
+    if (s32 + M < z) return 1;
+    if (s32 - M > z) return -1;
+    return 0;
+}
+
 template <typename R> struct RealLimits;
 template <> struct RealLimits<float> { static __device__ __forceinline__ float inf() { return INFINITY; } };
 template <> struct RealLimits<double> { static __device__ __forceinline__ double inf() { return (double)INFINITY; } };
@@ -100,6 +129,10 @@ constexpr int kDtWaves = PBD_DT_WAVES;   // waves per workgroup of the DT passes
 #define PBD_DT_RING 8
 #endif
 constexpr int kDtT = PBD_DT_RING;    // ring entries per lane (power of two)
+#ifndef PBD_DT_APPROX
+#define PBD_DT_APPROX 1
+#endif
+constexpr bool kDtApprox = PBD_DT_APPROX != 0;   // single-precision pre-test of the pop decision (quad_pop_test); 0: the round-2 loop
 
 // LDS layout of a wave's ring: [slot][z: 64 x R | s: 64 x R | v: 64 x int]; one address per lane, the rest
 // are immediate offsets.
@@ -178,6 +211,7 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
 {
     R cur[CH], nxt[CH];
     load(0, cur);
+    const float af = (float)a, bf = (float)b;       // a, b are floats widened to double (src/DynamicProgram.cpp:125-127): exact
     int k = 0, vk = 0;
     R zk = -RealLimits<R>::inf(), sk = cur[0];
     ring.lo = 0;
@@ -189,16 +223,34 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
             if (q >= 1 && q < N) {
                 const R sq = cur[i];
                 DT_STAT(0);
-                R s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
-                while (s <= zk && k > 0) {
-                    DT_STAT(1);
-                    --k;
-                    ring.template pop<BZ>(k, zk, sk, vk);
-                    s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
+                if constexpr (sizeof(R) == 4 && kDtApprox) {
+                    // pop while s(v[k], q) <= z[k] && k > 0 -- decided in single precision where that is certain (see
+                    // quad_pop_test), by the reference's expression otherwise; the intersection that is KEPT (pushed as z of the
+                    // new entry) is always the reference's
+                    for (;;) {
+                        int t = quad_pop_test<BZ>(af, bf, vk, q, (float)sk, (float)sq, (float)zk);
+                        if (__builtin_expect(t == 0, 0)) { DT_STAT(6); t = (quad_isect<R, BZ>(a, b, vk, q, sk, sq) <= zk) ? 1 : -1; }
+                        if (!(t > 0 && k > 0)) break;
+                        DT_STAT(1);
+                        --k;
+                        ring.template pop<BZ>(k, zk, sk, vk);
+                    }
+                    const R s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
+                    ring.push_below(k, zk, sk, vk);
+                    ++k;
+                    vk = q; zk = s; sk = sq;
+                } else {
+                    R s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
+                    while (s <= zk && k > 0) {
+                        DT_STAT(1);
+                        --k;
+                        ring.template pop<BZ>(k, zk, sk, vk);
+                        s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
+                    }
+                    ring.push_below(k, zk, sk, vk);
+                    ++k;
+                    vk = q; zk = s; sk = sq;
                 }
-                ring.push_below(k, zk, sk, vk);
-                ++k;
-                vk = q; zk = s; sk = sq;
             }
         }
 #pragma unroll
@@ -889,7 +941,7 @@ __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p)
 
 void launch_argmin_walk(const ArgminParams &p, bool f64, hipStream_t s)
 {
-    const int blocks = std::min((p.capacity + 63) / 64, 2048);
+    const int blocks = std::max(std::min((p.capacity + 63) / 64, 2048), 1);
     if (p.ptr8) {
         if (f64) hipLaunchKernelGGL((k_argmin_walk<double, uint8_t>), dim3(blocks), dim3(64), 0, s, p);
         else hipLaunchKernelGGL((k_argmin_walk<float, uint8_t>), dim3(blocks), dim3(64), 0, s, p);
