@@ -22,6 +22,10 @@
 
 using namespace pbd;
 
+namespace pbd {
+thread_local ProfHook *g_prof_hook = nullptr;
+}
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -141,7 +145,7 @@ struct Group {   // DT jobs of the parts of one tree depth + combine jobs of the
 };
 
 struct Prof {
-    bool on = false;
+    int on = 0;                      // 0: off, 1: every kernel, 2: the convolution only (pbd_profile_enable)
     struct Rec { int k; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -239,9 +243,9 @@ struct pbd_handle {
     struct CandBuf {
         DevBuf payload;
         int32_t *host = nullptr; size_t host_words = 0;
-        int guess = 1024;
         int copied = 0;                                   // records covered by the enqueued copy
     } cb;
+    int cand_guess = 1024;                                // records the next speculative copy covers (shared by every CandBuf)
 
     // pipelined host entry points (pbd_detect_batch_submit / _wait): two batches may be in flight
     struct Slot {
@@ -303,16 +307,22 @@ int guarded(pbd_handle *h, F &&body) noexcept
     }
 }
 
+// While a ProfScope is alive, every kernel launched by this thread is timed under kernel id `k` (see PBD_LAUNCH).
 struct ProfScope {
-    pbd_handle *h; int k; hipStream_t st; hipEvent_t a{}, b{};
-    ProfScope(pbd_handle *h_, int k_, hipStream_t st_) : h(h_), k(k_), st(st_)
+    pbd_handle *h; int k; ProfHook hook; ProfHook *prev;
+    static void take(void *ctx, hipEvent_t *a, hipEvent_t *b)
     {
-        if (h->prof.on) { a = h->prof.get(); b = h->prof.get(); (void)hipEventRecord(a, st); }
+        ProfScope *self = static_cast<ProfScope *>(ctx);
+        *a = self->h->prof.get(); *b = self->h->prof.get();
+        self->h->prof.recs.push_back({self->k, *a, *b});
     }
-    ~ProfScope()
+    ProfScope(pbd_handle *h_, int k_, hipStream_t) : h(h_), k(k_), hook{this, &ProfScope::take}, prev(g_prof_hook)
     {
-        if (h->prof.on) { (void)hipEventRecord(b, st); h->prof.recs.push_back({k, a, b}); }
+        if (h->prof.on == 1 || (h->prof.on == 2 && k == PBD_K_CONV)) g_prof_hook = &hook;
     }
+    ~ProfScope() { g_prof_hook = prev; }
+    ProfScope(const ProfScope &) = delete;
+    ProfScope &operator=(const ProfScope &) = delete;
 };
 
 // ---- plan construction -------------------------------------------------------------------------
@@ -1191,9 +1201,10 @@ int enqueue_argmin_readback(pbd_handle *h, Plan &P, int nframes, const float *d_
     HIPCHK(h, cb.payload.ensure(((size_t)cap * stride + 1) * sizeof(int32_t)));
     int rc = enqueue_argmin(h, P, nframes, d_scales, 0, cb.payload.as<int32_t>(), cap, st);
     if (rc != PBD_OK) return rc;
-    cb.copied = std::min(cb.guess, cap);
+    cb.copied = std::min(h->cand_guess, cap);
     const size_t words = 1 + (size_t)cb.copied * stride;
-    if ((rc = candbuf_host(h, cb, words)) != PBD_OK) return rc;
+    // the mirror is sized for twice the guess: growing it (hipHostFree + hipHostMalloc) synchronises the device
+    if (cb.host_words < words && (rc = candbuf_host(h, cb, 1 + (size_t)std::min(2 * (long long)cb.copied, (long long)cap) * stride)) != PBD_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(cb.host, cb.payload.p, words * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     return PBD_OK;
 }
@@ -1213,7 +1224,7 @@ int argmin_deliver(pbd_handle *h, pbd_handle::CandBuf &cb, hipStream_t st, int32
         HIPCHK(h, hipStreamSynchronize(st));
         cb.copied = n;
     }
-    cb.guess = std::min(cap, n + n / 4 + 256);
+    h->cand_guess = std::min(cap, std::max(n + n / 4 + 256, 1024));
     const int nout = std::min(n, std::max(capacity, 0));
     if (nout > 0) memcpy(cand, cb.host + 1, (size_t)nout * stride * sizeof(int32_t));
     *ncand = nout;
@@ -1915,7 +1926,7 @@ int pbd_profile_enable(pbd_handle *h, int on)
     return guarded(h, [&]() -> int {
         if (!h) return PBD_ERR_INVALID;
         h->prof.flush();
-        h->prof.on = on != 0;
+        h->prof.on = on == 2 ? 2 : (on != 0 ? 1 : 0);
         return PBD_OK;
     });
 }

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <string>
@@ -226,6 +227,27 @@ struct ArgminParams {
     long long ntotal;             // nframes * cell_per_frame * NC root cells
     int frame_offset;             // added to the `frame` field of every record (frames sharded over GPUs: global frame id)
 };
+
+// ---- kernel launches and their timing -------------------------------------------------------
+// Every kernel of the library is launched through PBD_LAUNCH.  While a profiling scope is open on the calling thread
+// (pbd_profile_enable; bench.py's roofline figures) the launch carries a start / stop event pair of its own
+// (hipExtLaunchKernelGGL): the timestamps are those of the kernel's dispatch packet, so nothing is inserted into the stream
+// between kernels.  (Bracketing a kernel with hipEventRecord puts a marker packet on either side of it: 10.5 us per
+// kernel boundary in the rocprofv3 trace of round 3, 0.45 ms of every 64-frame step -- profiles/r03_hd/README.md.)
+struct ProfHook {
+    void *ctx;
+    void (*take)(void *ctx, hipEvent_t *start, hipEvent_t *stop);
+};
+extern thread_local ProfHook *g_prof_hook;
+
+template <typename F, typename... Args>
+inline void launch_k(F kernel, const dim3 &grid, const dim3 &block, unsigned lds, hipStream_t s, Args... args)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (g_prof_hook) g_prof_hook->take(g_prof_hook->ctx, &a, &b);
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, s, a, b, 0, args...);
+}
+#define PBD_LAUNCH(kernel, grid, block, lds, stream, ...) ::pbd::launch_k(kernel, grid, block, lds, stream, __VA_ARGS__)
 
 // ---- launchers (pbd_kernels_*.hip) ---------------------------------------------------------
 void launch_resize(const PyrParams &p, int nframes, long long npix_resized, hipStream_t s);

@@ -411,14 +411,14 @@ static void launch_generic(const ConvParams &p, dim3 grid, hipStream_t s)
     const int PW = kConvTW + p.ksize - 1, PH = kConvTH + p.ksize - 1;
     const size_t lds = (size_t)32 * ((PH * PW) | 1) * sizeof(R);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_generic<R, FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_conv_generic<R, FMA>), grid, dim3(256), lds, s, p);
+    PBD_LAUNCH((k_conv_generic<R, FMA>), grid, dim3(256), lds, s, p);
 }
 
 template <bool FMA, int NW>
 static void launch_shapes(const ConvParams &p, int gy, int nframes, hipStream_t s)
 {
     const int nt = p.nshaped4[0] + p.nshaped4[1] + p.nshaped4[2] + p.nshaped4[3];
-    hipLaunchKernelGGL((k_conv<5, FMA, NW>), dim3(nt, gy, nframes), dim3(NW * 64), 0, s, p, static_cast<const float *>(p.wts),
+    PBD_LAUNCH((k_conv<5, FMA, NW>), dim3(nt, gy, nframes), dim3(NW * 64), 0, s, p, static_cast<const float *>(p.wts),
                        static_cast<const float *>(p.feat), static_cast<float *>(p.resp));
 }
 

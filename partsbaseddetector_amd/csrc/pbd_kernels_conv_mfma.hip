@@ -254,10 +254,10 @@ void launch_conv_mfma(const ConvParams &p, const void *wrec, bool f16, int nfram
     const int passes = (p.F + kMfmaFB - 1) / kMfmaFB;
     dim3 grid(nt, passes, nframes);
     if (f16)
-        hipLaunchKernelGGL((k_conv_mfma<5, true>), grid, dim3(256), 0, s, p, static_cast<const u32x4 *>(wrec),
+        PBD_LAUNCH((k_conv_mfma<5, true>), grid, dim3(256), 0, s, p, static_cast<const u32x4 *>(wrec),
                            static_cast<const float *>(p.feat), static_cast<float *>(p.resp));
     else
-        hipLaunchKernelGGL((k_conv_mfma<5, false>), grid, dim3(256), 0, s, p, static_cast<const u32x4 *>(wrec),
+        PBD_LAUNCH((k_conv_mfma<5, false>), grid, dim3(256), 0, s, p, static_cast<const u32x4 *>(wrec),
                            static_cast<const float *>(p.feat), static_cast<float *>(p.resp));
 }
 

@@ -389,9 +389,9 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
     dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
 #define PBD_ROWS(PT, BZ)                                                                                              \
     do {                                                                                                              \
-        if (f64) hipLaunchKernelGGL((k_dt_rows<double, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);          \
-        else if (p.resp_half) hipLaunchKernelGGL((k_dt_rows<float, true, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p); \
-        else hipLaunchKernelGGL((k_dt_rows<float, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);               \
+        if (f64) PBD_LAUNCH((k_dt_rows<double, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);          \
+        else if (p.resp_half) PBD_LAUNCH((k_dt_rows<float, true, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p); \
+        else PBD_LAUNCH((k_dt_rows<float, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);               \
     } while (0)
     if (p.ptr8) { if (p.bz_x) PBD_ROWS(uint8_t, true); else PBD_ROWS(uint8_t, false); }
     else { if (p.bz_x) PBD_ROWS(int16_t, true); else PBD_ROWS(int16_t, false); }
@@ -458,8 +458,8 @@ void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
     dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
 #define PBD_COLS(PT, BZ)                                                                                   \
     do {                                                                                                   \
-        if (f64) hipLaunchKernelGGL((k_dt_cols<double, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);      \
-        else hipLaunchKernelGGL((k_dt_cols<float, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);           \
+        if (f64) PBD_LAUNCH((k_dt_cols<double, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);      \
+        else PBD_LAUNCH((k_dt_cols<float, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);           \
     } while (0)
     if (p.ptr8) { if (p.bz_y) PBD_COLS(uint8_t, true); else PBD_COLS(uint8_t, false); }
     else { if (p.bz_y) PBD_COLS(int16_t, true); else PBD_COLS(int16_t, false); }
@@ -637,13 +637,13 @@ void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hip
 #define PBD_COMBINE(M)                                                                      \
     do {                                                                                    \
         if (p.ptr8) {                                                                                                      \
-            if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2, M, false, uint8_t>), g2, dim3(256), 0, s, p);            \
-            else if (p.resp_half) hipLaunchKernelGGL((k_dp_combine<float, 4, M, true, uint8_t>), g4, dim3(256), 0, s, p); \
-            else hipLaunchKernelGGL((k_dp_combine<float, 4, M, false, uint8_t>), g4, dim3(256), 0, s, p);                 \
+            if (f64) PBD_LAUNCH((k_dp_combine<double, 2, M, false, uint8_t>), g2, dim3(256), 0, s, p);            \
+            else if (p.resp_half) PBD_LAUNCH((k_dp_combine<float, 4, M, true, uint8_t>), g4, dim3(256), 0, s, p); \
+            else PBD_LAUNCH((k_dp_combine<float, 4, M, false, uint8_t>), g4, dim3(256), 0, s, p);                 \
         } else {                                                                                                           \
-            if (f64) hipLaunchKernelGGL((k_dp_combine<double, 2, M, false, int16_t>), g2, dim3(256), 0, s, p);            \
-            else if (p.resp_half) hipLaunchKernelGGL((k_dp_combine<float, 4, M, true, int16_t>), g4, dim3(256), 0, s, p); \
-            else hipLaunchKernelGGL((k_dp_combine<float, 4, M, false, int16_t>), g4, dim3(256), 0, s, p);                 \
+            if (f64) PBD_LAUNCH((k_dp_combine<double, 2, M, false, int16_t>), g2, dim3(256), 0, s, p);            \
+            else if (p.resp_half) PBD_LAUNCH((k_dp_combine<float, 4, M, true, int16_t>), g4, dim3(256), 0, s, p); \
+            else PBD_LAUNCH((k_dp_combine<float, 4, M, false, int16_t>), g4, dim3(256), 0, s, p);                 \
         }                                                                                                                  \
     } while (0)
     if (p.max_mix <= 2) PBD_COMBINE(2);
@@ -705,11 +705,11 @@ void launch_dp_combine_seq(const DpParams &p, int nsjobs, int nframes, bool f64,
     if (nsjobs == 0 || p.cell_per_frame == 0) return;
     dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), nsjobs, nframes);
     if (p.ptr8) {
-        if (f64) hipLaunchKernelGGL((k_dp_combine_seq<double, uint8_t>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_dp_combine_seq<float, uint8_t>), grid, dim3(256), 0, s, p);
+        if (f64) PBD_LAUNCH((k_dp_combine_seq<double, uint8_t>), grid, dim3(256), 0, s, p);
+        else PBD_LAUNCH((k_dp_combine_seq<float, uint8_t>), grid, dim3(256), 0, s, p);
     } else {
-        if (f64) hipLaunchKernelGGL((k_dp_combine_seq<double, int16_t>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_dp_combine_seq<float, int16_t>), grid, dim3(256), 0, s, p);
+        if (f64) PBD_LAUNCH((k_dp_combine_seq<double, int16_t>), grid, dim3(256), 0, s, p);
+        else PBD_LAUNCH((k_dp_combine_seq<float, int16_t>), grid, dim3(256), 0, s, p);
     }
 }
 
@@ -754,8 +754,8 @@ void launch_dp_root(const DpParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.cell_per_frame == 0) return;
     dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), p.NC, nframes);
-    if (f64) hipLaunchKernelGGL(k_dp_root<double>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_dp_root<float>, grid, dim3(256), 0, s, p);
+    if (f64) PBD_LAUNCH(k_dp_root<double>, grid, dim3(256), 0, s, p);
+    else PBD_LAUNCH(k_dp_root<float>, grid, dim3(256), 0, s, p);
 }
 
 // ---- argmin ------------------------------------------------------------------------------------
@@ -872,11 +872,11 @@ __global__ __launch_bounds__(kFindBlock) void k_argmin_emit(ArgminParams p)
 
 void launch_argmin_find(const ArgminParams &p, bool f64, hipStream_t s)
 {   // p.nblk = ceil(p.ntotal / kFindSpan) >= 1; p.blk holds nblk ints
-    if (f64) hipLaunchKernelGGL(k_argmin_count<double>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
-    else hipLaunchKernelGGL(k_argmin_count<float>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
-    hipLaunchKernelGGL(k_argmin_scan, dim3(1), dim3(1024), 0, s, p);
-    if (f64) hipLaunchKernelGGL(k_argmin_emit<double>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
-    else hipLaunchKernelGGL(k_argmin_emit<float>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
+    if (f64) PBD_LAUNCH(k_argmin_count<double>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
+    else PBD_LAUNCH(k_argmin_count<float>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
+    PBD_LAUNCH(k_argmin_scan, dim3(1), dim3(1024), 0, s, p);
+    if (f64) PBD_LAUNCH(k_argmin_emit<double>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
+    else PBD_LAUNCH(k_argmin_emit<float>, dim3(p.nblk), dim3(kFindBlock), 0, s, p);
 }
 int argmin_find_span() { return kFindSpan; }
 
@@ -943,11 +943,11 @@ void launch_argmin_walk(const ArgminParams &p, bool f64, hipStream_t s)
 {
     const int blocks = std::max(std::min((p.capacity + 63) / 64, 2048), 1);
     if (p.ptr8) {
-        if (f64) hipLaunchKernelGGL((k_argmin_walk<double, uint8_t>), dim3(blocks), dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((k_argmin_walk<float, uint8_t>), dim3(blocks), dim3(64), 0, s, p);
+        if (f64) PBD_LAUNCH((k_argmin_walk<double, uint8_t>), dim3(blocks), dim3(64), 0, s, p);
+        else PBD_LAUNCH((k_argmin_walk<float, uint8_t>), dim3(blocks), dim3(64), 0, s, p);
     } else {
-        if (f64) hipLaunchKernelGGL((k_argmin_walk<double, int16_t>), dim3(blocks), dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((k_argmin_walk<float, int16_t>), dim3(blocks), dim3(64), 0, s, p);
+        if (f64) PBD_LAUNCH((k_argmin_walk<double, int16_t>), dim3(blocks), dim3(64), 0, s, p);
+        else PBD_LAUNCH((k_argmin_walk<float, int16_t>), dim3(blocks), dim3(64), 0, s, p);
     }
 }
 

@@ -193,13 +193,13 @@ __global__ __launch_bounds__(256) void k_resize_t(PyrParams p, long long npix)
 void launch_resize(const PyrParams &p, int nframes, long long npix, hipStream_t s)
 {
     dim3 grid((unsigned)((npix + 255) / 256), nframes);
-    if (p.depth == kDepth16U) hipLaunchKernelGGL((k_resize_t<uint16_t, float>), grid, dim3(256), 0, s, p, npix);
-    else if (p.depth == kDepth32F) hipLaunchKernelGGL((k_resize_t<float, float>), grid, dim3(256), 0, s, p, npix);
-    else if (p.depth == kDepth64F) hipLaunchKernelGGL((k_resize_t<double, double>), grid, dim3(256), 0, s, p, npix);
+    if (p.depth == kDepth16U) PBD_LAUNCH((k_resize_t<uint16_t, float>), grid, dim3(256), 0, s, p, npix);
+    else if (p.depth == kDepth32F) PBD_LAUNCH((k_resize_t<float, float>), grid, dim3(256), 0, s, p, npix);
+    else if (p.depth == kDepth64F) PBD_LAUNCH((k_resize_t<double, double>), grid, dim3(256), 0, s, p, npix);
     else if (p.cn == 3) {
         dim3 grid4((unsigned)((npix + 1023) / 1024), nframes);
-        hipLaunchKernelGGL(k_resize4, grid4, dim3(256), 0, s, p, npix);
-    } else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, p, npix);
+        PBD_LAUNCH(k_resize4, grid4, dim3(256), 0, s, p, npix);
+    } else PBD_LAUNCH(k_resize, grid, dim3(256), 0, s, p, npix);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -310,10 +310,10 @@ void launch_pyrdown_range(const PyrParams &p, int nframes, int first_level, int 
                           long long npix, hipStream_t s)
 {
     dim3 grid((unsigned)((npix + 255) / 256), nframes);
-    if (p.depth == kDepth16U) hipLaunchKernelGGL((k_pyrdown_t<uint16_t, int>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
-    else if (p.depth == kDepth32F) hipLaunchKernelGGL((k_pyrdown_t<float, float>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
-    else if (p.depth == kDepth64F) hipLaunchKernelGGL((k_pyrdown_t<double, double>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
-    else hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+    if (p.depth == kDepth16U) PBD_LAUNCH((k_pyrdown_t<uint16_t, int>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+    else if (p.depth == kDepth32F) PBD_LAUNCH((k_pyrdown_t<float, float>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+    else if (p.depth == kDepth64F) PBD_LAUNCH((k_pyrdown_t<double, double>), grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
+    else PBD_LAUNCH(k_pyrdown, grid, dim3(256), 0, s, p, first_level, last_level, base, npix);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,30 +804,30 @@ void launch_hog_hist(const HogParams &p, int nframes, bool f64, hipStream_t s)
     if (!f64 && p.depth == kDepth8U && p.cn == 3 && (p.sbin == 4 || p.sbin == 8) && !two_pass) {
         if (p.nhtiles == 0) return;
         dim3 grid((unsigned)p.nhtiles, nframes);
-        if (p.sbin == 4) hipLaunchKernelGGL((k_hog_tile<4, kHogTBX, 16>), grid, dim3(kHogTBX * 16), 0, s, p);
-        else hipLaunchKernelGGL((k_hog_tile<8, kHogTBX, 8>), grid, dim3(kHogTBX * 8), 0, s, p);
+        if (p.sbin == 4) PBD_LAUNCH((k_hog_tile<4, kHogTBX, 16>), grid, dim3(kHogTBX * 16), 0, s, p);
+        else PBD_LAUNCH((k_hog_tile<8, kHogTBX, 8>), grid, dim3(kHogTBX * 8), 0, s, p);
         return;
     }
     dim3 gridp((unsigned)((p.pix_per_frame + 255) / 256), nframes);
 #define PBD_GRAD(PT)                                                                            \
     do {                                                                                        \
-        if (f64) hipLaunchKernelGGL((k_hog_grad_t<double, PT>), gridp, dim3(256), 0, s, p);     \
-        else hipLaunchKernelGGL((k_hog_grad_t<float, PT>), gridp, dim3(256), 0, s, p);          \
+        if (f64) PBD_LAUNCH((k_hog_grad_t<double, PT>), gridp, dim3(256), 0, s, p);     \
+        else PBD_LAUNCH((k_hog_grad_t<float, PT>), gridp, dim3(256), 0, s, p);          \
     } while (0)
     if (p.depth == kDepth16U) PBD_GRAD(uint16_t);
     else if (p.depth == kDepth32F) PBD_GRAD(float);
     else if (p.depth == kDepth64F) PBD_GRAD(double);
-    else if (f64) hipLaunchKernelGGL(k_hog_grad<double>, gridp, dim3(256), 0, s, p);
+    else if (f64) PBD_LAUNCH(k_hog_grad<double>, gridp, dim3(256), 0, s, p);
     else if (p.cn == 3) {
         dim3 grid4((unsigned)((p.pix_per_frame + 1023) / 1024), nframes);
-        hipLaunchKernelGGL(k_hog_grad4, grid4, dim3(256), 0, s, p);
-    } else hipLaunchKernelGGL(k_hog_grad<float>, gridp, dim3(256), 0, s, p);
+        PBD_LAUNCH(k_hog_grad4, grid4, dim3(256), 0, s, p);
+    } else PBD_LAUNCH(k_hog_grad<float>, gridp, dim3(256), 0, s, p);
 #undef PBD_GRAD
     dim3 grid((unsigned)((p.blk_per_frame + 255) / 256), nframes);
-    if (f64) hipLaunchKernelGGL((k_hog_hist<double, 0>), grid, dim3(256), 0, s, p);
-    else if (p.sbin == 4) hipLaunchKernelGGL((k_hog_hist<float, 4>), grid, dim3(256), 0, s, p);
-    else if (p.sbin == 8) hipLaunchKernelGGL((k_hog_hist<float, 8>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_hog_hist<float, 0>), grid, dim3(256), 0, s, p);
+    if (f64) PBD_LAUNCH((k_hog_hist<double, 0>), grid, dim3(256), 0, s, p);
+    else if (p.sbin == 4) PBD_LAUNCH((k_hog_hist<float, 4>), grid, dim3(256), 0, s, p);
+    else if (p.sbin == 8) PBD_LAUNCH((k_hog_hist<float, 8>), grid, dim3(256), 0, s, p);
+    else PBD_LAUNCH((k_hog_hist<float, 0>), grid, dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,8 +900,8 @@ void launch_hog_feat(const HogParams &p, int nframes, bool f64, hipStream_t s)
 {
     if (p.cell_per_frame == 0) return;
     dim3 grid((unsigned)((p.cell_per_frame + 255) / 256), nframes);
-    if (f64) hipLaunchKernelGGL(k_hog_feat<double>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_hog_feat<float>, grid, dim3(256), 0, s, p);
+    if (f64) PBD_LAUNCH(k_hog_feat<double>, grid, dim3(256), 0, s, p);
+    else PBD_LAUNCH(k_hog_feat<float>, grid, dim3(256), 0, s, p);
 }
 
 }  // namespace pbd

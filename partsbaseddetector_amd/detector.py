@@ -143,7 +143,8 @@ class Handle:
                                  component=int(r[1]), frame=int(r[0]), level=int(r[2]), root=(int(r[3]), int(r[4]))))
         return out
 
-    def profile(self, on: bool = True):
+    def profile(self, on=True):
+        """on: False / 0 off, True / 1 every kernel, 2 the convolution only (pbd_profile_enable)"""
         self.check(self.lib.pbd_profile_enable(self.h, int(on)))
         self.check(self.lib.pbd_profile_reset(self.h))
 
