@@ -207,6 +207,10 @@ struct pbd_handle {
         int K = 0, nf = 0, Fpad = 0;
         DevBuf wts;                  // real-typed weights of the class
         DevTable<int> fmap;          // class-local index -> filter id (empty when the class is the whole bank in order)
+        // k_conv3 (float, 5 x 5): the class cut into units of 2..8 filters, weights [unit][32][25][8]
+        DevBuf wts3;
+        DevTable<int> unit_f0, unit_ql;
+        int nunits = 0;
     };
     std::vector<ConvClass> conv_classes;
     DevBuf d_wrec;                   // bf16 hi/lo weight records of the matrix-core path
@@ -638,6 +642,32 @@ float host_h2f(uint16_t hv)
 }
 
 // ---- model tables --------------------------------------------------------------------------------
+// Work items of k_conv3: the nf filters of a size class cut into units of 8 / 6 (and at most one of 4 or 2) filters so that
+// `nw` waves taking units largest-first finish together.  156 filters, 6 waves: 6 x 8 + 18 x 6 -- every wave 8 + 6 + 6 + 6.
+void conv_units(int nf, int nw, std::vector<int> &f0, std::vector<int> &ql)
+{
+    const int P = (nf + 1) / 2;                            // filter pairs (an odd bank ends in a padding lane)
+    double best = 1e30;
+    int ba = 0, bb = 0, bc = 0;
+    for (int a = P / 4; a >= 0; --a)
+        for (int c = 0; c <= 2; ++c) {                     // c pairs in one last small unit (0: none)
+            const int rest = P - 4 * a - c;
+            if (rest < 0 || rest % 3) continue;
+            const int b = rest / 3;
+            // largest-first hand-out to nw equally fast waves; a unit costs its pairs + a fixed overhead (window reads, stores)
+            std::vector<double> load(nw, 0.0);
+            auto give = [&](int n, double cost) { for (int i = 0; i < n; ++i) *std::min_element(load.begin(), load.end()) += cost; };
+            give(a, 4 + 0.2); give(b, 3 + 0.2); if (c) give(1, c + 0.2);
+            const double span = *std::max_element(load.begin(), load.end()) + (c ? 0.01 : 0.0);    // ties: no small unit
+            if (span < best - 1e-9) { best = span; ba = a; bb = b; bc = c; }
+        }
+    f0.clear(); ql.clear();
+    int f = 0;
+    for (int i = 0; i < ba; ++i) { f0.push_back(f); ql.push_back(8); f += 8; }
+    for (int i = 0; i < bb; ++i) { f0.push_back(f); ql.push_back(6); f += 6; }
+    if (bc) { f0.push_back(f); ql.push_back(2 * bc); f += 2 * bc; }
+}
+
 template <typename R>
 int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, const int *ksize)
 {
@@ -658,7 +688,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         std::vector<pbd_handle::ConvClass> classes;
         DevBuf wrec;
         bool keep = false;
-        ~NewBank() { if (!keep) { for (auto &c : classes) { c.wts.release(); c.fmap.release(); } wrec.release(); } }
+        ~NewBank() { if (!keep) { for (auto &c : classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); } wrec.release(); } }
     } nb;
     nb.classes.assign(sizes.size(), pbd_handle::ConvClass{});
     for (size_t ci = 0; ci < sizes.size(); ++ci) {
@@ -685,6 +715,23 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         HIPCHK(h, C.wts.ensure(w.size() * sizeof(R)));
         HIPCHK(h, hipMemcpy(C.wts.p, w.data(), w.size() * sizeof(R), hipMemcpyHostToDevice));
         if (sizes.size() > 1) HIPCHK(h, C.fmap.upload(ids));
+        if (fast5) {
+            std::vector<int> uf0, uql;
+            const char *env_nw = getenv("PBD_CONV3_UNITS_NW");     // experiments: cut the units for another wave count
+            conv_units(C.nf, env_nw && atoi(env_nw) > 0 ? atoi(env_nw) : kConv3NW, uf0, uql);
+            C.nunits = (int)uf0.size();
+            std::vector<float> w3((size_t)C.nunits * 32 * KK * 8, 0.0f);
+            for (int u = 0; u < C.nunits; ++u)
+                for (int q = 0; q < uql[u] && uf0[u] + q < C.nf; ++q) {
+                    const R *src = static_cast<const R *>(filters[ids[uf0[u] + q]]);
+                    for (int t = 0; t < KK; ++t)
+                        for (int c = 0; c < 32; ++c) w3[(((size_t)u * 32 + c) * KK + t) * 8 + q] = (float)src[(size_t)t * 32 + c];
+                }
+            HIPCHK(h, C.wts3.ensure(w3.size() * sizeof(float)));
+            HIPCHK(h, hipMemcpy(C.wts3.p, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIPCHK(h, C.unit_f0.upload(uf0));
+            HIPCHK(h, C.unit_ql.upload(uql));
+        }
     }
     const int Fpad = (nfilters + kConvQ - 1) / kConvQ * kConvQ;
     if (mfma) {
@@ -723,7 +770,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         HIPCHK(h, hipMemcpy(nb.wrec.p, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
     }
     // commit
-    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); }
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); }
     h->conv_classes.swap(nb.classes);
     nb.classes.clear();
     if (mfma) { h->d_wrec.release(); h->d_wrec = nb.wrec; nb.wrec = DevBuf{}; }
@@ -1054,6 +1101,10 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
         // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
         const long long wgs = (long long)P.ntiles * nb;
         cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
+        static const bool use_v3 = !(getenv("PBD_CONV_V3") && atoi(getenv("PBD_CONV_V3")) == 0);
+        cp.wts3 = (use_v3 && C.nunits > 0) ? C.wts3.p : nullptr;
+        cp.unit_f0 = C.unit_f0.d; cp.unit_ql = C.unit_ql.d; cp.nunits = C.nunits;
+        cp.units_per_block = wgs >= 1024 ? std::max(C.nunits, 1) : std::max(1, (int)((long long)C.nunits * wgs / 1024));
         if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16)
             launch_conv_mfma(cp, h->d_wrec.p, h->cfg.conv_mode == PBD_CONV_MFMA_F16, nb, st);
         else launch_conv(cp, nb, h->f64, st);
@@ -1444,7 +1495,7 @@ void pbd_destroy(pbd_handle *h)
                       &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->find_blk,
                       &h->scales_tmp})
         b->release();
-    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); }
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); }
     h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_walk_off.release();
     h->d_rjobs.release(); h->d_walk.release();
     for (auto &g : h->groups) { g.d_jobs.release(); g.d_childs.release(); g.d_cjobs.release(); g.d_sjobs.release(); }

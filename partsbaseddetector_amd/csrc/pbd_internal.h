@@ -109,6 +109,10 @@ constexpr int kMaxMix = 8;
 // bytes of one spilled PAIR of envelope-stack entries {T sa, sb, za; unsigned vv;} (natural alignment of T)
 constexpr size_t kStkPairF32 = 16, kStkPairF64 = 32;
 constexpr int kConvTW = 32, kConvTH = 8, kConvQ = 8;
+#ifndef PBD_CONV3_NW
+#define PBD_CONV3_NW 8
+#endif
+constexpr int kConv3NW = PBD_CONV3_NW;   // waves per workgroup of k_conv3
 
 // ---- launch parameter blocks ---------------------------------------------------------------
 struct PyrParams {
@@ -158,6 +162,10 @@ struct ConvParams {
     int nf, Fpad, ksize;          // this launch: filters of one size class, padded to kConvQ, their size
     const int *fmap;              // class-local filter index -> response plane (NULL: identity, the single-class case)
     int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
+    // round-3 kernel (k_conv3): the bank cut into units of 2 / 4 / 6 / 8 filters, weights [unit][32][25][8]; NULL: k_conv
+    const void *wts3;
+    const int *unit_f0, *unit_ql; // first filter (class-local index) and live filters of a unit
+    int nunits, units_per_block;
     int c31_zero;                 // the features come from this library's HOG: channel 31 is 0 in every cell of the image
     int frame0;
     long long cell_per_frame;

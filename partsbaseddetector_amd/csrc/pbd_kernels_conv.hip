@@ -310,6 +310,267 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const float *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: the same tile, the same arithmetic and the same stage pipeline, but the WEIGHTS COME THROUGH THE SCALAR UNIT
+// (s_load_dwordx8 into SGPRs, used as the scalar operand of v_pk_mul_f32) instead of through wave-private LDS slices and
+// 80 VGPRs of double-buffered broadcast reads.  That takes the kernel from 237 to <= 168 VGPRs, i.e. from two to THREE
+// waves per SIMD (two workgroups of six waves per CU): a register-only stream of the packed pairs runs at 4.63 cycles per
+// instruction with two waves per SIMD, 4.45 with three (tools/probes/vgpr_banks.hip), and a third wave fills the issue
+// slots the other two leave while they wait (VALU was busy 89 % of the cycles with two).
+// Work items: with six waves the 19.5 groups of eight filters no longer divide evenly, so the host cuts the bank into
+// UNITS of 8 or 6 filters (156 = 6 x 8 + 18 x 6: every wave gets 8 + 6 + 6 + 6 when the SIMDs are evenly loaded, and the
+// hand-out through the LDS counter -- larger units first -- evens it out when they are not).  Weights: [unit][32][25][8]
+// floats, a unit's unused upper lanes zero and never multiplied (QL = live filters of the unit: 2, 4, 6 or 8).
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef const v8f __attribute__((address_space(4))) cfloat8;
+
+template <int K, bool FMA, int NW, int S>
+__device__ __forceinline__ void conv_tile3(const ConvParams &p, const float *__restrict__ wts, const float *__restrict__ featp,
+                                           float *__restrict__ respp, float *sm, int *next_u, const ConvTile tile)
+{
+    constexpr bool WRAP = S == 3;
+    constexpr int TW = WRAP ? 64 : kConvTW >> S, TH = WRAP ? 4 : kConvTH << S, P = 4;
+    static_assert(TW * TH == 256 && TH % P == 0, "a wave of 64 lanes x 4 rows covers the tile");
+    static_assert(K == 5, "the stage pipeline below is written for 5 x 5 filters");
+    constexpr int PW = WRAP ? TW + 2 * (K - 1) : TW + K - 1, PH = TH + K - 1;
+    constexpr int PLANE = (PH * PW) | 1;   // odd plane stride: conflict-free staging writes
+
+    const int frame = p.frame0 + blockIdx.z;
+    const LevelDesc d = p.lv[tile.level];
+    const int H = d.rows, W = d.cols;
+    constexpr int a = K / 2;
+    const int t = threadIdx.x;
+    const float *feat = featp + ((size_t)frame * p.cell_per_frame + d.cell_off) * 32;
+    const int la = WRAP ? min(W - tile.x0, 64) : 0;
+
+    {   // stage the haloed tile channel-planar (as conv_tile)
+        constexpr int CPP = NW * 8, NIT = (PH * PW + CPP - 1) / CPP, UB = 6;
+        const int c4 = t & 7, cell0 = t >> 3;
+        const v4f border = (c4 == 7) ? v4f{0.0f, 0.0f, 0.0f, 1.0f} : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it0 = 0; it0 < NIT; it0 += UB) {
+            v4f v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int ci = (it0 + u) * CPP + cell0;
+                const int cy = ci / PW, cx = ci - cy * PW;
+                int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
+                if (WRAP) {
+                    const bool second = cx >= la + K - 1;
+                    gy = 4 * (tile.y0 + (second ? 1 : 0)) + cy - a;
+                    gx = second ? cx - (la + K - 1) - a : tile.x0 + cx - a;
+                }
+                v[u] = border;
+                if (it0 + u < NIT && ci < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    v[u] = *reinterpret_cast<const v4f *>(feat + ((size_t)gy * W + gx) * 32 + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int ci = (it0 + u) * CPP + cell0;
+                if (it0 + u < NIT && ci < PH * PW) {
+                    float *dst = sm + (c4 * 4) * PLANE + ci;
+                    dst[0] = v[u].x; dst[PLANE] = v[u].y; dst[2 * PLANE] = v[u].z; dst[3 * PLANE] = v[u].w;
+                }
+            }
+        }
+    }
+    const int u0 = blockIdx.y * p.units_per_block;
+    const int u1 = min(u0 + p.units_per_block, p.nunits);
+    if (t == 0) *next_u = u0;
+    __syncthreads();
+
+    const int lane = t & 63;
+    // the lane's place in the tile: LDS column / row of its window, level coordinates of its first output.  Evaluated again
+    // after the channel loop (a handful of integer operations) instead of being carried through it in registers: at four
+    // waves per SIMD the loop has 128 of them
+    auto lane_geom = [&](int &px, int &py, int &x, int &y) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const bool second = WRAP && ln >= la;
+        px = WRAP ? ln + (second ? K - 1 : 0) : ln & (TW - 1);
+        py = WRAP ? 0 : (ln >> (WRAP ? 0 : 5 - S)) * P;
+        x = WRAP ? (second ? ln - la : tile.x0 + ln) : tile.x0 + px;
+        y = WRAP ? 4 * (tile.y0 + (second ? 1 : 0)) : tile.y0 + py;
+    };
+    const size_t HW = (size_t)H * W;
+    const float *sp0;
+    {
+        int px, py, x, y;
+        lane_geom(px, py, x, y);
+        sp0 = sm + py * PW + px;
+    }
+    const bool skip31 = WRAP ? (!FMA && p.c31_zero && la >= 64 && 4 * tile.y0 >= a && tile.x0 >= a && 4 * tile.y0 + TH + a <= H && tile.x0 + TW + a <= W)
+                             : (!FMA && p.c31_zero && tile.y0 >= a && tile.x0 >= a && tile.y0 + TH + a <= H && tile.x0 + TW + a <= W);
+
+    auto run_unit = [&](auto ql_tag, const int u, const int f0) {
+        constexpr int QL = decltype(ql_tag)::value, QH = QL / 2;
+        // the unit's weights, 8 floats per (channel, tap): wave-uniform addresses in the constant address space -> s_load
+        cfloat8 *wc = (cfloat8 *)(wts + (size_t)u * (32 * K * K * 8));
+        v2f r[P][QH];
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+            for (int q = 0; q < QH; ++q) r[pp][q] = v2f{0.0f, 0.0f};
+        float Ft[P + K - 1][K];
+        v8f Wt[2][K];                  // SGPRs: tap row in use | tap row being fetched
+        auto load_row = [&](int c, int rr) {
+            const float *sp = sp0 + c * PLANE + rr * PW;
+#pragma unroll
+            for (int j = 0; j < K; ++j) Ft[rr][j] = sp[j];
+        };
+        auto load_w = [&](int buf, int c, int i) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) Wt[buf][j] = wc[(c * K + i) * K + j];
+        };
+        v2f s[P][QH];
+        auto zero_s = [&]() {
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int q = 0; q < QH; ++q) s[pp][q] = v2f{0.0f, 0.0f};
+        };
+        auto add_s = [&]() {
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int q = 0; q < QH; ++q) r[pp][q] = r[pp][q] + s[pp][q];
+        };
+        auto comp = [&](int wbi, int i) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                v2f w[QH];
+#pragma unroll
+                for (int q = 0; q < QH; ++q) w[q] = v2f{Wt[wbi][j][2 * q], Wt[wbi][j][2 * q + 1]};
+                // RB rows at a time: at least four products, then their additions -- an addition issues >= 16 cycles after its
+                // product (with three pairs per row a row-by-row order would put it 12 cycles after, and stall)
+                constexpr int RB = QH >= 4 ? 1 : QH == 3 ? 2 : QH == 2 ? 2 : 4;
+#pragma unroll
+                for (int p0 = 0; p0 < P; p0 += RB) {
+                    const bool first = (i == 0 && j == 0);      // see conv_tile: the `0 +` of a channel's first tap cannot reach the response
+                    const v2f zero2 = v2f{0.0f, 0.0f};
+                    if (FMA) {
+#pragma unroll
+                        for (int pr = 0; pr < RB; ++pr) {
+                            const v2f f = v2f{Ft[p0 + pr + i][j], Ft[p0 + pr + i][j]};
+#pragma unroll
+                            for (int q = 0; q < QH; ++q) s[p0 + pr][q] = __builtin_elementwise_fma(w[q], f, first ? zero2 : s[p0 + pr][q]);
+                        }
+                    } else {
+                        v2f tq[RB][QH];
+#pragma unroll
+                        for (int pr = 0; pr < RB; ++pr) {
+                            const v2f f = v2f{Ft[p0 + pr + i][j], Ft[p0 + pr + i][j]};
+#pragma unroll
+                            for (int q = 0; q < QH; ++q) tq[pr][q] = w[q] * f;
+                        }
+#pragma unroll
+                        for (int pr = 0; pr < RB; ++pr)
+#pragma unroll
+                            for (int q = 0; q < QH; ++q) s[p0 + pr][q] = first ? tq[pr][q] : s[p0 + pr][q] + tq[pr][q];
+                    }
+                }
+            }
+        };
+#define PBD_PIN3()                                                                                                         \
+    do {                                                                                                                   \
+        if constexpr (QL == 8)                                                                                             \
+            asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]),    \
+                         "+v"(s[1][2]), "+v"(s[1][3]), "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[2][2]), "+v"(s[2][3]),         \
+                         "+v"(s[3][0]), "+v"(s[3][1]), "+v"(s[3][2]), "+v"(s[3][3])::"memory");                            \
+        else if constexpr (QL == 6)                                                                                        \
+            asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]),    \
+                         "+v"(s[2][0]), "+v"(s[2][1]), "+v"(s[2][2]), "+v"(s[3][0]), "+v"(s[3][1]), "+v"(s[3][2])::"memory"); \
+        else if constexpr (QL == 4)                                                                                        \
+            asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[2][0]), "+v"(s[2][1]),    \
+                         "+v"(s[3][0]), "+v"(s[3][1])::"memory");                                                          \
+        else                                                                                                               \
+            asm volatile("" : "+v"(s[0][0]), "+v"(s[1][0]), "+v"(s[2][0]), "+v"(s[3][0])::"memory");                       \
+    } while (0)
+#define PBD_STAGE3(LOADS, WB, I)                 \
+    do {                                         \
+        LOADS;                                   \
+        PBD_PIN3();                              \
+        __builtin_amdgcn_sched_barrier(0);       \
+        comp(WB, I);                             \
+        PBD_PIN3();                              \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#pragma unroll
+        for (int rr = 0; rr < P; ++rr) load_row(0, rr);
+        load_w(0, 0, 0);
+        zero_s();
+        // one channel: the tap rows alternate between the two weight buffers, so two channels make the pattern repeat
+#define PBD_CHANNEL3(c, cn, B0, B1)                                                                                                \
+    do {                                                                                                                          \
+        PBD_STAGE3(load_row((c), 4); load_w(B1, (c), 1), B0, 0);                                                                  \
+        PBD_STAGE3(load_row((c), 5); load_w(B0, (c), 2), B1, 1);                                                                  \
+        PBD_STAGE3(load_row((c), 6); load_w(B1, (c), 3), B0, 2);                                                                  \
+        PBD_STAGE3(load_row((c), 7); load_w(B0, (c), 4), B1, 3);                                                                  \
+        PBD_STAGE3(load_row((cn), 0); load_row((cn), 1); load_row((cn), 2); load_row((cn), 3); load_w(B1, (cn), 0), B0, 4);       \
+        add_s();                                                                                                                  \
+    } while (0)
+        const int cpairs = skip31 ? 30 : 32;
+#pragma clang loop unroll(disable)
+        for (int c = 0; c < cpairs; c += 2) {
+            const int c2 = min(c + 2, 31);
+            PBD_CHANNEL3(c, c + 1, 0, 1);
+            PBD_CHANNEL3(c + 1, c2, 1, 0);
+        }
+        if (skip31) PBD_CHANNEL3(30, 31, 0, 1);
+#undef PBD_CHANNEL3
+#undef PBD_STAGE3
+#undef PBD_PIN3
+        int px, py, x, y;
+        lane_geom(px, py, x, y);
+        float *respg = respp + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)y * W + x;
+        if (f0 + QL <= p.nf && p.fmap == nullptr) {
+            float *rg = respg + (size_t)f0 * HW;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                if (x < W && y + pp < H) {
+#pragma unroll
+                    for (int q = 0; q < QL; ++q) rg[(size_t)q * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
+                }
+            }
+        } else if (x < W) {
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                if (y + pp < H) {
+#pragma unroll
+                    for (int q = 0; q < QL; ++q) {
+                        const int f = f0 + q;
+                        if (f < p.nf) respg[(size_t)(p.fmap ? p.fmap[f] : f) * HW + (size_t)pp * W] = r[pp][q / 2][q & 1];
+                    }
+                }
+            }
+        }
+    };
+    for (;;) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(next_u, 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= u1) break;
+        const int f0 = p.unit_f0[u], ql = p.unit_ql[u];       // wave-uniform (scalar loads)
+        if (ql == 8) run_unit(std::integral_constant<int, 8>{}, u, f0);
+        else if (ql == 6) run_unit(std::integral_constant<int, 6>{}, u, f0);
+        else if (ql == 4) run_unit(std::integral_constant<int, 4>{}, u, f0);
+        else run_unit(std::integral_constant<int, 2>{}, u, f0);
+    }
+}
+
+template <int K, bool FMA, int NW>
+__global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv3(ConvParams p, const float *__restrict__ wts, const float *__restrict__ featp,
+                                                   float *__restrict__ respp)
+{
+    __shared__ __attribute__((aligned(16))) float sm[32 * 577 + 3];
+    __shared__ int next_u;
+    const int b = blockIdx.x;
+    const ConvTile tile = p.shaped4[b];
+    if (b < p.nshaped4[0]) conv_tile3<K, FMA, NW, 0>(p, wts, featp, respp, sm, &next_u, tile);
+    else if (b < p.nshaped4[0] + p.nshaped4[1]) conv_tile3<K, FMA, NW, 1>(p, wts, featp, respp, sm, &next_u, tile);
+    else if (b < p.nshaped4[0] + p.nshaped4[1] + p.nshaped4[2]) conv_tile3<K, FMA, NW, 2>(p, wts, featp, respp, sm, &next_u, tile);
+    else conv_tile3<K, FMA, NW, 3>(p, wts, featp, respp, sm, &next_u, tile);
+}
+
 // one launch covers all three tile shapes: the shape is uniform per workgroup (tiles are sorted by shape)
 template <int K, bool FMA, int NW>
 __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv(ConvParams p, const float *__restrict__ wts, const float *__restrict__ featp,
@@ -415,6 +676,15 @@ static void launch_generic(const ConvParams &p, dim3 grid, hipStream_t s)
 }
 
 template <bool FMA, int NW>
+static void launch_shapes3(const ConvParams &p, int nframes, hipStream_t s)
+{
+    const int nt = p.nshaped4[0] + p.nshaped4[1] + p.nshaped4[2] + p.nshaped4[3];
+    const int gy = (p.nunits + p.units_per_block - 1) / p.units_per_block;
+    PBD_LAUNCH((k_conv3<5, FMA, NW>), dim3(nt, gy, nframes), dim3(NW * 64), 0, s, p, static_cast<const float *>(p.wts3),
+               static_cast<const float *>(p.feat), static_cast<float *>(p.resp));
+}
+
+template <bool FMA, int NW>
 static void launch_shapes(const ConvParams &p, int gy, int nframes, hipStream_t s)
 {
     const int nt = p.nshaped4[0] + p.nshaped4[1] + p.nshaped4[2] + p.nshaped4[3];
@@ -428,7 +698,10 @@ void launch_conv(const ConvParams &p, int nframes, bool f64, hipStream_t s)
     const int ngroups = p.Fpad / kConvQ;
     const int gy = (ngroups + p.groups_per_block - 1) / p.groups_per_block;
     dim3 grid(p.ntiles, gy, nframes);
-    if (!f64 && p.ksize == 5) {
+    if (!f64 && p.ksize == 5 && p.wts3 != nullptr) {
+        // round 3: weights through the scalar unit, six waves per workgroup (three per SIMD)
+        if (p.fma) launch_shapes3<true, kConv3NW>(p, nframes, s); else launch_shapes3<false, kConv3NW>(p, nframes, s);
+    } else if (!f64 && p.ksize == 5) {
         // 4 waves per workgroup, so that the two resident workgroups put 2 waves on every SIMD (5 or 6 leave the
         // SIMDs unevenly loaded: 54.7 / 50.9 ms vs 46.0 ms per 64-frame step when this was measured)
         if (p.fma) launch_shapes<true, 4>(p, gy, nframes, s); else launch_shapes<false, 4>(p, gy, nframes, s);
