@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <memory>
 #include <numeric>
 #include <new>
@@ -117,15 +118,19 @@ struct Plan {
     DevTable<ResizeTabY> d_taby;
     DevTable<ResizeTabXf> d_tabxf;   // the same mapping with float coefficients (16U / 32F / 64F images)
     DevTable<ResizeTabYf> d_tabyf;
-    DevTable<ConvTile> d_tiles, d_shaped, d_shaped4, d_htiles;
-    int nshaped[3] = {0, 0, 0}, nshaped4[4] = {0, 0, 0, 0}, nhtiles = 0;
+    DevTable<ConvTile> d_tiles, d_shaped, d_htiles;
+    int nshaped[3] = {0, 0, 0}, nhtiles = 0;
+    // strip-sequence tiles of the exact 5 x 5 convolution, per number of frames in a launch (built on first use)
+    std::map<int, DevTable<ConvSegTile>> segtiles;
     DevTable<int> d_row2level, d_rowoff, d_col2level, d_coloff;
     DevTable<long long> d_stk_row_off, d_stk_col_off;
     long long stk_per_jf = 0;
     DevTable<float> d_scales;
     void release()
     {
-        d_lv.release(); d_tabx.release(); d_taby.release(); d_tabxf.release(); d_tabyf.release(); d_tiles.release(); d_shaped.release(); d_shaped4.release(); d_htiles.release();
+        d_lv.release(); d_tabx.release(); d_taby.release(); d_tabxf.release(); d_tabyf.release(); d_tiles.release(); d_shaped.release(); d_htiles.release();
+        for (auto &kv : segtiles) kv.second.release();
+        segtiles.clear();
         d_row2level.release(); d_rowoff.release(); d_col2level.release(); d_coloff.release(); d_scales.release();
         d_stk_row_off.release(); d_stk_col_off.release();
     }
@@ -209,7 +214,7 @@ struct pbd_handle {
         DevTable<int> fmap;          // class-local index -> filter id (empty when the class is the whole bank in order)
         // k_conv3 (float, 5 x 5): the class cut into units of 2..8 filters, weights [unit][32][25][8]
         DevBuf wts3;
-        DevTable<int> unit_f0, unit_ql;
+        DevTable<int> unit_f0, unit_ql, unit_woff;
         int nunits = 0;
     };
     std::vector<ConvClass> conv_classes;
@@ -359,11 +364,38 @@ static void cover_level(int l, int rows, int cols, std::vector<ConvTile> *shaped
     }
 }
 
+// Tiles of the exact 5 x 5 convolution for a launch of `nb` frames (pbd_kernels_conv.hip): the strips of four rows of every
+// level of every frame, left to right, form one sequence of positions; a tile takes 64 consecutive positions, in at most
+// kConvMaxSeg runs (a run stays inside one strip) -- when a fourth run would be needed the tile ends early.
+void build_seg_tiles(const std::vector<LevelDesc> &lv, int nb, std::vector<ConvSegTile> &out)
+{
+    out.clear();
+    ConvSegTile cur{};
+    int lanes = 0;
+    auto flush = [&]() { if (cur.nseg) out.push_back(cur); cur = ConvSegTile{}; lanes = 0; };
+    for (int f = 0; f < nb; ++f)
+        for (int l = 0; l < (int)lv.size(); ++l) {
+            const int H = lv[l].rows, W = lv[l].cols;
+            if (H <= 0 || W <= 0) continue;
+            for (int st = 0; st < (H + 3) / 4; ++st)
+                for (int x = 0; x < W;) {
+                    if (cur.nseg == kConvMaxSeg || lanes == 64) flush();
+                    const int take = std::min(W - x, 64 - lanes);
+                    cur.len[cur.nseg] = take;
+                    cur.seg[cur.nseg] = ConvSeg{f, l, st, x};
+                    cur.nseg += 1;
+                    lanes += take;
+                    x += take;
+                }
+        }
+    flush();
+}
+
 hipError_t finish_plan_tables(Plan &P, int sbin)
 {
     // flat row / column lookup and conv tiles over the feature maps
     std::vector<int> row2level, rowoff(P.nlevels + 1, 0), col2level, coloff(P.nlevels + 1, 0);
-    std::vector<ConvTile> tiles, shaped[3], shaped4[4], htiles;
+    std::vector<ConvTile> tiles, shaped[3], htiles;
     P.quad_per_frame = 0;
     for (int l = 0; l < P.nlevels; ++l) {
         P.lv[l].quad_off = P.quad_per_frame;
@@ -379,16 +411,6 @@ hipError_t finish_plan_tables(Plan &P, int sbin)
             for (int y0 = 0; y0 < d.rows; y0 += kConvTH)
                 for (int x0 = 0; x0 < d.cols; x0 += kConvTW) tiles.push_back({l, y0, x0});
             cover_level(l, d.rows, d.cols, shaped);
-            // exact kernel: the same cover, or wrapped 64 x 4 tiles where those are fewer (levels at least 64 cells wide)
-            std::vector<ConvTile> lvl[3];
-            cover_level(l, d.rows, d.cols, lvl);
-            const long long npos = (long long)d.cols * ((d.rows + 3) / 4);
-            const long long nwrap = (npos + 63) / 64;
-            if (d.cols >= 64 && nwrap < (long long)(lvl[0].size() + lvl[1].size() + lvl[2].size())) {
-                for (long long t = 0; t < nwrap; ++t) shaped4[3].push_back({l, (int)(t * 64 / d.cols), (int)(t * 64 % d.cols)});
-            } else {
-                for (int k = 0; k < 3; ++k) shaped4[k].insert(shaped4[k].end(), lvl[k].begin(), lvl[k].end());
-            }
         }
     }
     {
@@ -421,15 +443,12 @@ hipError_t finish_plan_tables(Plan &P, int sbin)
     P.stk_per_jf = std::max(tot_r, tot_c);
     std::vector<ConvTile> all;
     for (int k = 0; k < 3; ++k) { P.nshaped[k] = (int)shaped[k].size(); all.insert(all.end(), shaped[k].begin(), shaped[k].end()); }
-    std::vector<ConvTile> all4;
-    for (int k = 0; k < 4; ++k) { P.nshaped4[k] = (int)shaped4[k].size(); all4.insert(all4.end(), shaped4[k].begin(), shaped4[k].end()); }
     hipError_t e;
     if ((e = P.d_stk_row_off.upload(srow)) != hipSuccess) return e;
     if ((e = P.d_stk_col_off.upload(scol)) != hipSuccess) return e;
     if ((e = P.d_lv.upload(P.lv)) != hipSuccess) return e;
     if ((e = P.d_tiles.upload(tiles)) != hipSuccess) return e;
     if ((e = P.d_shaped.upload(all)) != hipSuccess) return e;
-    if ((e = P.d_shaped4.upload(all4)) != hipSuccess) return e;
     if ((e = P.d_htiles.upload(htiles)) != hipSuccess) return e;
     if ((e = P.d_row2level.upload(row2level)) != hipSuccess) return e;
     if ((e = P.d_rowoff.upload(rowoff)) != hipSuccess) return e;
@@ -688,7 +707,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         std::vector<pbd_handle::ConvClass> classes;
         DevBuf wrec;
         bool keep = false;
-        ~NewBank() { if (!keep) { for (auto &c : classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); } wrec.release(); } }
+        ~NewBank() { if (!keep) { for (auto &c : classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); } wrec.release(); } }
     } nb;
     nb.classes.assign(sizes.size(), pbd_handle::ConvClass{});
     for (size_t ci = 0; ci < sizes.size(); ++ci) {
@@ -720,13 +739,17 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
             const char *env_nw = getenv("PBD_CONV3_UNITS_NW");     // experiments: cut the units for another wave count
             conv_units(C.nf, env_nw && atoi(env_nw) > 0 ? atoi(env_nw) : kConv3NW, uf0, uql);
             C.nunits = (int)uf0.size();
-            std::vector<float> w3((size_t)C.nunits * 32 * KK * 8, 0.0f);
+            std::vector<int> uoff(C.nunits, 0);
+            size_t tot = 0;
+            for (int u = 0; u < C.nunits; ++u) { uoff[u] = (int)tot; tot += (size_t)32 * KK * uql[u]; }
+            std::vector<float> w3(tot + 16, 0.0f);       // (slack: the last tap row is fetched once more past the last channel)
             for (int u = 0; u < C.nunits; ++u)
                 for (int q = 0; q < uql[u] && uf0[u] + q < C.nf; ++q) {
                     const R *src = static_cast<const R *>(filters[ids[uf0[u] + q]]);
                     for (int t = 0; t < KK; ++t)
-                        for (int c = 0; c < 32; ++c) w3[(((size_t)u * 32 + c) * KK + t) * 8 + q] = (float)src[(size_t)t * 32 + c];
+                        for (int c = 0; c < 32; ++c) w3[uoff[u] + ((size_t)c * KK + t) * uql[u] + q] = (float)src[(size_t)t * 32 + c];
                 }
+            HIPCHK(h, C.unit_woff.upload(uoff));
             HIPCHK(h, C.wts3.ensure(w3.size() * sizeof(float)));
             HIPCHK(h, hipMemcpy(C.wts3.p, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
             HIPCHK(h, C.unit_f0.upload(uf0));
@@ -770,7 +793,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         HIPCHK(h, hipMemcpy(nb.wrec.p, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
     }
     // commit
-    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); }
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); }
     h->conv_classes.swap(nb.classes);
     nb.classes.clear();
     if (mfma) { h->d_wrec.release(); h->d_wrec = nb.wrec; nb.wrec = DevBuf{}; }
@@ -1074,6 +1097,17 @@ void launch_features(pbd_handle *h, Plan &P, const void *d_frames, int cn, int f
     h->feat_c31_zero = true;
 }
 
+int ensure_seg_tiles(pbd_handle *h, Plan &P, int nb)
+{
+    if (nb < 1 || P.segtiles.count(nb)) return PBD_OK;
+    std::vector<ConvSegTile> tiles;
+    build_seg_tiles(P.lv, nb, tiles);
+    DevTable<ConvSegTile> t;
+    HIPCHK(h, t.upload(tiles));
+    P.segtiles[nb] = t;
+    return PBD_OK;
+}
+
 int alloc_conv(pbd_handle *h, Plan &P, int nframes)
 {
     if (!h->filters_set) return fail(h, PBD_ERR_STATE, "pdf() before setFilters()");
@@ -1087,8 +1121,14 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     cp.lv = P.d_lv.d; cp.tiles = P.d_tiles.d; cp.ntiles = P.ntiles;
     cp.shaped = P.d_shaped.d;
     for (int k = 0; k < 3; ++k) cp.nshaped[k] = P.nshaped[k];
-    cp.shaped4 = P.d_shaped4.d;
-    for (int k = 0; k < 4; ++k) cp.nshaped4[k] = P.nshaped4[k];
+    cp.segtiles = nullptr; cp.nsegtiles = 0;
+    if (!h->f64 && h->cfg.conv_mode != PBD_CONV_MFMA && h->cfg.conv_mode != PBD_CONV_MFMA_F16) {
+        auto it = P.segtiles.find(nb);
+        if (it == P.segtiles.end()) {            // first launch of this many frames on this plan (alloc_conv built it)
+            return;
+        }
+        cp.segtiles = it->second.d; cp.nsegtiles = (int)it->second.n;
+    }
     cp.F = h->F; cp.frame0 = f0;
     cp.cell_per_frame = P.cell_per_frame;
     cp.feat = h->feat.p; cp.resp = h->resp.p;
@@ -1101,9 +1141,8 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
         // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
         const long long wgs = (long long)P.ntiles * nb;
         cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
-        static const bool use_v3 = !(getenv("PBD_CONV_V3") && atoi(getenv("PBD_CONV_V3")) == 0);
-        cp.wts3 = (use_v3 && C.nunits > 0) ? C.wts3.p : nullptr;
-        cp.unit_f0 = C.unit_f0.d; cp.unit_ql = C.unit_ql.d; cp.nunits = C.nunits;
+        cp.wts3 = C.wts3.p;
+        cp.unit_f0 = C.unit_f0.d; cp.unit_ql = C.unit_ql.d; cp.unit_woff = C.unit_woff.d; cp.nunits = C.nunits;
         cp.units_per_block = wgs >= 1024 ? std::max(C.nunits, 1) : std::max(1, (int)((long long)C.nunits * wgs / 1024));
         if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16)
             launch_conv_mfma(cp, h->d_wrec.p, h->cfg.conv_mode == PBD_CONV_MFMA_F16, nb, st);
@@ -1193,6 +1232,7 @@ int run_conv(pbd_handle *h, Plan &P, int nframes)
 {
     int rc = alloc_conv(h, P, nframes);
     if (rc != PBD_OK) return rc;
+    if ((rc = ensure_seg_tiles(h, P, nframes)) != PBD_OK) return rc;
     launch_conv_stage(h, P, 0, nframes, h->stream);
     HIPCHK(h, hipGetLastError());
     h->have_resp = true;
@@ -1317,6 +1357,8 @@ int enqueue_detect(pbd_handle *h, int nframes, const void *d_frames, int rows, i
     const int chunk = dp_chunk_frames(h, *P, want);
     if ((rc = alloc_features(h, *P, nframes, cn)) != PBD_OK) return rc;
     if ((rc = alloc_conv(h, *P, nframes)) != PBD_OK) return rc;
+    if ((rc = ensure_seg_tiles(h, *P, std::min(chunk, nframes))) != PBD_OK) return rc;
+    if (nframes % chunk && (rc = ensure_seg_tiles(h, *P, nframes % chunk)) != PBD_OK) return rc;
     if ((rc = alloc_dp(h, *P, nframes, chunk)) != PBD_OK) return rc;
     const int nchunks = (nframes + chunk - 1) / chunk;
     while ((int)h->chunk_events.size() < nchunks + 1) {
@@ -1412,6 +1454,21 @@ int pbd_debug_cover_level(int rows, int cols, int *out, int capacity)
     });
 }
 
+// the exact convolution's strip-sequence tiles for `nb` frames of the given feature-map sizes (host-only, no GPU needed):
+// out[i] = {nseg, len0, len1, len2, then per segment frame, level, strip, x0} = 16 ints per tile; returns the tile count
+int pbd_debug_seg_tiles(int nlevels, const int *rows, const int *cols, int nb, int *out, int capacity)
+{
+    return guarded(nullptr, [&]() -> int {
+        std::vector<LevelDesc> lv(nlevels);
+        for (int l = 0; l < nlevels; ++l) { memset(&lv[l], 0, sizeof lv[l]); lv[l].rows = rows[l]; lv[l].cols = cols[l]; }
+        std::vector<ConvSegTile> tiles;
+        build_seg_tiles(lv, nb, tiles);
+        static_assert(sizeof(ConvSegTile) == 16 * sizeof(int), "a tile record is 16 ints");
+        for (size_t i = 0; i < tiles.size() && (int)i < capacity; ++i) memcpy(out + 16 * i, &tiles[i], sizeof(ConvSegTile));
+        return (int)tiles.size();
+    });
+}
+
 // runs a body that throws inside the ABI guard (host-only): 0 = std::bad_alloc, 1 = std::length_error from an absurd
 // std::vector size, 2 = another std::exception; returns the status code the guard produced
 int pbd_debug_guard_selftest(int kind)
@@ -1495,7 +1552,7 @@ void pbd_destroy(pbd_handle *h)
                       &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->find_blk,
                       &h->scales_tmp})
         b->release();
-    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); }
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); }
     h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_walk_off.release();
     h->d_rjobs.release(); h->d_walk.release();
     for (auto &g : h->groups) { g.d_jobs.release(); g.d_childs.release(); g.d_cjobs.release(); g.d_sjobs.release(); }

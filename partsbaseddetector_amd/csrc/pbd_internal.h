@@ -43,6 +43,11 @@ typedef HogCoordT<float> HogCoord;
 typedef HogCoordT<double> HogCoordD;
 
 struct ConvTile { int level; int y0, x0; };
+// Tile of the exact 5 x 5 convolution: 64 consecutive positions of the sequence "every strip of four rows of every level of
+// every frame of the launch, left to right", as up to kConvMaxSeg runs inside one strip each (pbd_kernels_conv.hip)
+constexpr int kConvMaxSeg = 3;
+struct ConvSeg { int frame, level, strip, x0; };            // frame: index within the launch
+struct ConvSegTile { int nseg; int len[kConvMaxSeg]; ConvSeg seg[kConvMaxSeg]; };
 // tile of HOG blocks handled by one workgroup of the fused gradient + histogram kernel: kHogTBX x hog_tile_rows(sbin)
 constexpr int kHogTBX = 16;
 inline int hog_tile_rows(int sbin) { return sbin <= 4 ? 16 : 8; }
@@ -153,18 +158,16 @@ struct ConvParams {
     int ntiles;
     const ConvTile *shaped;       // mixed-shape tiling of the exact 5x5 kernel: 32x8 tiles, then 16x16, then 8x32
     int nshaped[3];
-    // the exact 5x5 kernel's own cover: the three shapes, then WRAPPED tiles (shape 3) -- 64 consecutive positions of the
-    // sequence "strip 0 (rows 0..3) left to right, strip 1, ..." of a level at least 64 cells wide; such a tile runs over the
-    // right edge into the next strip instead of leaving lanes idle there.  ConvTile::y0 = strip, x0 = first column
-    const ConvTile *shaped4;
-    int nshaped4[4];
+    const ConvSegTile *segtiles;  // the exact / FMA 5x5 kernel's cover of the whole launch (all frames)
+    int nsegtiles;
     int F;                        // response planes per cell block (all filters of the bank)
     int nf, Fpad, ksize;          // this launch: filters of one size class, padded to kConvQ, their size
     const int *fmap;              // class-local filter index -> response plane (NULL: identity, the single-class case)
     int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
-    // round-3 kernel (k_conv3): the bank cut into units of 2 / 4 / 6 / 8 filters, weights [unit][32][25][8]; NULL: k_conv
+    // k_conv3: the bank cut into units of 2 / 4 / 6 / 8 filters, weights per unit [32][25][QL]
     const void *wts3;
-    const int *unit_f0, *unit_ql; // first filter (class-local index) and live filters of a unit
+    const int *unit_f0, *unit_ql; // first filter (class-local index) and filters of a unit
+    const int *unit_woff;         // float offset of a unit's weights in wts3
     int nunits, units_per_block;
     int c31_zero;                 // the features come from this library's HOG: channel 31 is 0 in every cell of the image
     int frame0;

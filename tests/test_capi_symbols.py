@@ -118,3 +118,68 @@ def test_no_exception_crosses_the_abi(lib):
     assert lib.pbd_debug_guard_selftest(2) == -1          # PBD_ERR_INVALID
     assert b"selftest" in lib.pbd_last_error(None)
     assert lib.pbd_debug_guard_selftest(3) == 0
+
+
+def test_conv_strip_sequence_tiles_cover_every_position_once():
+    """Host logic of the exact convolution's tiles (pbd_capi.hip: build_seg_tiles), no GPU needed: the strips of four rows
+    of every level of every frame form one sequence of positions; every position is in exactly one tile, a tile has at
+    most 64 positions in at most three runs (each inside one strip), runs of a tile are consecutive in the sequence, and the
+    tile count equals an independent greedy count.  640x480: 569 tiles per frame (549.7 = no idle lane at all)."""
+    import ctypes as C
+    import numpy as np
+    from partsbaseddetector_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    fn = lib.pbd_debug_seg_tiles
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int]
+
+    def tiles_of(levels, nb):
+        rows = np.array([h for h, w in levels], np.int32)
+        cols = np.array([w for h, w in levels], np.int32)
+        cap = 200000
+        buf = np.zeros(16 * cap, np.int32)
+        n = fn(len(levels), rows.ctypes.data_as(C.POINTER(C.c_int)), cols.ctypes.data_as(C.POINTER(C.c_int)), nb,
+               buf.ctypes.data_as(C.POINTER(C.c_int)), cap)
+        assert 0 <= n <= cap
+        return buf[:16 * n].reshape(n, 16)
+
+    def greedy(levels, nb):
+        tiles = lanes = segs = 0
+        for f in range(nb):
+            for h, w in levels:
+                if h * w == 0:
+                    continue
+                for st in range((h + 3) // 4):
+                    x = 0
+                    while x < w:
+                        if segs == 3 or lanes == 64:
+                            tiles, lanes, segs = tiles + 1, 0, 0
+                        take = min(w - x, 64 - lanes)
+                        lanes, segs, x = lanes + take, segs + 1, x + take
+        return tiles + (1 if lanes else 0)
+
+    rng = np.random.default_rng(3)
+    cases = [([(118, 158), (110, 147), (5, 7), (0, 9), (3, 2), (1, 1)], 3), ([(4, 64)], 2), ([(1, 200)], 1), ([(9, 1)], 5)]
+    cases += [([tuple(int(v) for v in rng.integers(0, 90, 2)) for _ in range(int(rng.integers(1, 8)))], int(rng.integers(1, 4))) for _ in range(20)]
+    for levels, nb in cases:
+        t = tiles_of(levels, nb)
+        seq = []                                        # the sequence of (frame, level, strip, x) in tile order
+        for r in t:
+            ns = int(r[0])
+            assert 1 <= ns <= 3 and 0 < int(r[1:1 + ns].sum()) <= 64 and not r[1 + ns:4].any()
+            for k in range(ns):
+                f, l, st, x0 = (int(v) for v in r[4 + 4 * k: 8 + 4 * k])
+                h, w = levels[l]
+                assert 0 <= f < nb and 0 <= st < (h + 3) // 4 and 0 <= x0 and x0 + r[1 + k] <= w
+                seq += [(f, l, st, x) for x in range(x0, x0 + int(r[1 + k]))]
+        want = [(f, l, st, x) for f in range(nb) for l, (h, w) in enumerate(levels) if h * w for st in range((h + 3) // 4) for x in range(w)]
+        assert seq == want
+        assert len(t) == greedy(levels, nb)
+    # the bench workload: 46 levels of a 640x480 frame (SURVEY Appendix B), 64 frames
+    from oracle import oracle
+    lr, lc, _ = oracle.pyramid_plan(480, 640, 4, 10)
+    levels = [tuple(int(v) for v in oracle.hog_dims(int(r), int(c), 4)) for r, c in zip(lr, lc)]
+    cells = sum(h * w for h, w in levels)
+    assert cells == 140725
+    n64 = len(tiles_of(levels, 64))
+    assert 568.5 <= n64 / 64 <= 569.5 and n64 / 64 < 597, n64 / 64
