@@ -440,7 +440,6 @@ hipError_t finish_plan_tables(Plan &P, int sbin)
         scol.push_back(tot_c);
         tot_c += 64LL * ((mx + 1) / 2);
     }
-    srow.push_back(tot_r); scol.push_back(tot_c);      // end of the last wave's region (a lane's share = region / 64)
     P.stk_per_jf = std::max(tot_r, tot_c);
     std::vector<ConvTile> all;
     for (int k = 0; k < 3; ++k) { P.nshaped[k] = (int)shaped[k].size(); all.insert(all.end(), shaped[k].begin(), shaped[k].end()); }

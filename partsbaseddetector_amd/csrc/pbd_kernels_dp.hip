@@ -56,59 +56,6 @@ __device__ __forceinline__ R quad_val(double a, double b, int x, R y)
     if (BZ) return (R)(a * (double)__mul24(x, x) + (double)y);
     return (R)((a * (double)__mul24(x, x) + b * (double)x) + (double)y);     // |x| < 2^16
 }
-// The pop decision `s <= z[k]` of the envelope scan (DistanceTransform.hpp:162) WITHOUT the double-precision intersection,
-// whenever single precision can already tell: s32 is the same quotient evaluated in fp32 and M bounds |s32 - s| for the
-// exactly rounded s the reference computes --
-//   numerator (y1 - y0) [- b*d] + a*sq: every fp32 operation is correctly rounded, so its error is at most
-//   2^-23 (|y1 - y0| + |b*d| + |a*sq|); denominator 2a*d, v_rcp_f32 (1 ulp) and the product add 2^-22 relative; the
-//   reference's own rounding of s to float adds 2^-24: |s32 - s| <= 3.5 * 2^-23 * X with X = (|dy| + |b d| + |a sq|) / |2 a d|.
-// M = 2^-20 * X leaves a factor 2.3 on top.  Returns +1 (s <= z for certain), -1 (s > z for certain) or 0 (undecided: within
-// M of z, or anything non-finite -- every comparison with a NaN is false): the caller then evaluates the reference's
-// expression, so the decision taken is ALWAYS the reference's.  The wave runs 2.45 pop iterations per element of which a lane
-// needs 0.71 (tools/dt_stats.sh); each used to pay a full fp64 divide.  Only for T = float (the inputs are then exact in fp32).
-template <bool BZ>
-__device__ __forceinline__ int quad_pop_test(float a, float b, int x0, int x1, float y0, float y1, float z)
-{
-    const int dx = x1 - x0;
-    const float dd = (float)dx;
-    const float sq = (float)(int)__umul24((unsigned)dx, (unsigned)(x1 + x0));     // < 2^24: exact
-    const float dy = y1 - y0;
-    const float t = a * sq;
-    float num, mag;
-    if (BZ) { num = dy + t; mag = fabsf(dy) + fabsf(t); }
-    else { const float u = b * dd; num = (dy - u) + t; mag = (fabsf(dy) + fabsf(u)) + fabsf(t); }
-    const float r = __builtin_amdgcn_rcpf((2.0f * a) * dd);
-    const float s32 = num * r;
-    const float M = (mag * fabsf(r)) * 9.5367431640625e-07f;     // 2^-20
-    if (s32 + M < z) return 1;
-    if (s32 - M > z) return -1;
-    return 0;
-}
-
-// The same quotient as a value: s32 and M with |s32 - s| <= M for the exactly rounded s of the reference (bound as above).
-template <bool BZ>
-__device__ __forceinline__ float quad_isect32(float a, float b, int x0, int x1, float y0, float y1, float &M)
-{
-    const int dx = x1 - x0;
-    const float dd = (float)dx;
-    const float sq = (float)(int)__umul24((unsigned)dx, (unsigned)(x1 + x0));     // < 2^24: exact
-    const float dy = y1 - y0;
-    const float t = a * sq;
-    float num, mag;
-    if (BZ) { num = dy + t; mag = fabsf(dy) + fabsf(t); }
-    else { const float u = b * dd; num = (dy - u) + t; mag = (fabsf(dy) + fabsf(u)) + fabsf(t); }
-    const float r = __builtin_amdgcn_rcpf((2.0f * a) * dd);
-    M = (mag * fabsf(r)) * 9.5367431640625e-07f;     // 2^-20
-    return num * r;
-}
-// Bound on the margin of a STORED approximate intersection z32 = s32(v', v) (v' < v its lower, v its upper entry), from what
-// is still at hand when it is compared later: X = |dy / den| + |b / 2a| + (v' + v) / 2 and dy / den = s - (v' + v) / 2 + b / 2a,
-// so X <= |s| + 2 v + |b / a| <= |z32| + M + 2 v + |b / a|.  c0 = 1 + |b / a| per job.
-__device__ __forceinline__ float quad_zmargin(float z32, int v, float c0)
-{
-    return (fabsf(z32) + (float)(2 * v) + c0) * 9.6e-07f;     // 2^-20 * 1.007: covers the M inside the bound
-}
-
 template <typename R> struct RealLimits;
 template <> struct RealLimits<float> { static __device__ __forceinline__ float inf() { return INFINITY; } };
 template <> struct RealLimits<double> { static __device__ __forceinline__ double inf() { return (double)INFINITY; } };
@@ -153,23 +100,6 @@ constexpr int kDtWaves = PBD_DT_WAVES;   // waves per workgroup of the DT passes
 #define PBD_DT_RING 8
 #endif
 constexpr int kDtT = PBD_DT_RING;    // ring entries per lane (power of two)
-#ifndef PBD_DT_APPROX
-#define PBD_DT_APPROX 2
-#endif
-// 0: every intersection in double precision, as the reference (round 2)
-// 1: the pop decision pre-tested in single precision (quad_pop_test), the kept intersections exact
-// 2: LAZY -- the envelope carries single-precision intersections z32 with error bounds; every comparison the reference makes
-//    (s <= z[k] in the scan, z[k] < os in the read-out) is decided from them when the bounds allow, and by the reference's own
-//    double-precision expressions on the reference's operands otherwise (about 2 in 10^4 comparisons) -- so every decision
-//    is the reference's, while no fp64 division is left on the common path.  T = float only.
-constexpr int kDtMode = PBD_DT_APPROX;
-#ifndef PBD_DT_LANEMAJOR
-#define PBD_DT_LANEMAJOR 1
-#endif
-// spill stack layout inside a wave's region: 1 = every lane's records contiguous ([lane][pair]: a lane's consecutive spills and
-// reloads touch the same 64-byte sector), 0 = [pair][lane] (round 1 / 2: coalesced only when all lanes sit at the same depth)
-constexpr int kDtStkStride = PBD_DT_LANEMAJOR ? 1 : 64;
-constexpr bool kDtApprox = kDtMode == 1;
 
 // LDS layout of a wave's ring: [slot][z: 64 x R | s: 64 x R | v: 64 x int]; one address per lane, the rest
 // are immediate offsets.
@@ -190,12 +120,12 @@ struct DtRing {
         if (idx - lo >= kDtT) {   // ring full: spill its two oldest entries lo, lo + 1 as one record
             DT_STAT(3);
             const int sl = lo & (kDtT - 1);
-            g[(size_t)(lo >> 1) * kDtStkStride] = StkPairT<R>{s(sl), s(sl + 1), z(sl), (unsigned)v(sl) | ((unsigned)v(sl + 1) << 16)};
+            g[(size_t)(lo >> 1) * 64] = StkPairT<R>{s(sl), s(sl + 1), z(sl), (unsigned)v(sl) | ((unsigned)v(sl + 1) << 16)};
             lo += 2;
         }
         z(slot) = zk; s(slot) = sk; v(slot) = vk;
     }
-    template <bool BZ, bool LAZY = false>
+    template <bool BZ>
     __device__ __forceinline__ void pop(int idx, R &zk, R &sk, int &vk)
     {   // entry `idx` becomes the top
         // the ring slot is read unconditionally (always a valid LDS address) so that the common case is
@@ -207,13 +137,12 @@ struct DtRing {
             DT_STAT(4);
             // the ring is empty (idx == lo - 1, odd): reload the pair (lo-2, lo-1); the lower entry goes back
             // into the ring, the upper one is the new top and gets its z recomputed
-            const StkPairT<R> e = g[(size_t)((lo - 2) >> 1) * kDtStkStride];
+            const StkPairT<R> e = g[(size_t)((lo - 2) >> 1) * 64];
             const int va = (int)(e.vv & 0xffffu), vb = (int)(e.vv >> 16);
             const int sl = (lo - 2) & (kDtT - 1);
             z(sl) = e.za; s(sl) = e.sa; v(sl) = va;
             sk = e.sb; vk = vb;
-            if constexpr (LAZY) { float m_; zk = (R)quad_isect32<BZ>((float)a, (float)b, va, vb, (float)e.sa, (float)e.sb, m_); }
-            else zk = BZ ? quad_isect<R, true>(a, b, va, vb, e.sa, e.sb) : quad_isect<R, false>(a, b, va, vb, e.sa, e.sb);   // as computed when entry lo-1 was pushed onto entry lo-2
+            zk = BZ ? quad_isect<R, true>(a, b, va, vb, e.sa, e.sb) : quad_isect<R, false>(a, b, va, vb, e.sa, e.sb);   // as computed when entry lo-1 was pushed onto entry lo-2
             lo -= 2;
         }
     }
@@ -249,17 +178,6 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
 {
     R cur[CH], nxt[CH];
     load(0, cur);
-    const float af = (float)a, bf = (float)b;       // a, b are floats widened to double (src/DynamicProgram.cpp:125-127): exact
-    const float c0 = 1.0f + fabsf(bf / af);
-    // LAZY mode: the exact z of the current top k >= 1 -- the reference's z[k] = intersection of entries k-1 and k, evaluated
-    // with the reference's expression on demand.  Entry k-1 is in the ring, or (ring empty) the upper half of the last spilled pair
-    auto exact_ztop = [&](int kk, int vtop, R stop) -> R {
-        const int idx = kk - 1;
-        R s_; int v_;
-        if (idx >= ring.lo) { const int slot = idx & (kDtT - 1); s_ = ring.s(slot); v_ = ring.v(slot); }
-        else { const StkPairT<R> e = ring.g[(size_t)((ring.lo - 2) >> 1) * kDtStkStride]; s_ = e.sb; v_ = (int)(e.vv >> 16); }
-        return quad_isect<R, BZ>(a, b, v_, vtop, s_, stop);
-    };
     int k = 0, vk = 0;
     R zk = -RealLimits<R>::inf(), sk = cur[0];
     ring.lo = 0;
@@ -271,54 +189,16 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
             if (q >= 1 && q < N) {
                 const R sq = cur[i];
                 DT_STAT(0);
-                if constexpr (sizeof(R) == 4 && kDtMode == 2) {
-                    // LAZY (see kDtMode): zk is z32 here.  pop while s(v[k], q) <= z[k] && k > 0
-                    float s32, Ms;
-                    for (;;) {
-                        s32 = quad_isect32<BZ>(af, bf, vk, q, (float)sk, (float)sq, Ms);
-                        if (k == 0) break;
-                        const float d = s32 - (float)zk, M = Ms + quad_zmargin((float)zk, vk, c0);
-                        bool popit = d < -M;                               // s <= z for certain
-                        if (__builtin_expect(!popit && !(d > M), 0)) {     // neither certain (or not finite): the reference's expressions
-                            DT_STAT(6);
-                            popit = quad_isect<R, BZ>(a, b, vk, q, sk, sq) <= exact_ztop(k, vk, sk);
-                        }
-                        if (!popit) break;
-                        DT_STAT(1);
-                        --k;
-                        ring.template pop<BZ, true>(k, zk, sk, vk);
-                    }
-                    ring.push_below(k, zk, sk, vk);
-                    ++k;
-                    vk = q; zk = (R)s32; sk = sq;
-                } else if constexpr (sizeof(R) == 4 && kDtApprox) {
-                    // pop while s(v[k], q) <= z[k] && k > 0 -- decided in single precision where that is certain (see
-                    // quad_pop_test), by the reference's expression otherwise; the intersection that is KEPT (pushed as z of the
-                    // new entry) is always the reference's
-                    for (;;) {
-                        int t = quad_pop_test<BZ>(af, bf, vk, q, (float)sk, (float)sq, (float)zk);
-                        if (__builtin_expect(t == 0, 0)) { DT_STAT(6); t = (quad_isect<R, BZ>(a, b, vk, q, sk, sq) <= zk) ? 1 : -1; }
-                        if (!(t > 0 && k > 0)) break;
-                        DT_STAT(1);
-                        --k;
-                        ring.template pop<BZ>(k, zk, sk, vk);
-                    }
-                    const R s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
-                    ring.push_below(k, zk, sk, vk);
-                    ++k;
-                    vk = q; zk = s; sk = sq;
-                } else {
-                    R s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
-                    while (s <= zk && k > 0) {
-                        DT_STAT(1);
-                        --k;
-                        ring.template pop<BZ>(k, zk, sk, vk);
-                        s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
-                    }
-                    ring.push_below(k, zk, sk, vk);
-                    ++k;
-                    vk = q; zk = s; sk = sq;
+                R s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
+                while (s <= zk && k > 0) {
+                    DT_STAT(1);
+                    --k;
+                    ring.template pop<BZ>(k, zk, sk, vk);
+                    s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
                 }
+                ring.push_below(k, zk, sk, vk);
+                ++k;
+                vk = q; zk = s; sk = sq;
             }
         }
 #pragma unroll
@@ -345,22 +225,10 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
             if (q < N) {
                 const R osf = (R)(os0 + q);
                 DT_STAT(5);
-                if constexpr (sizeof(R) == 4 && kDtMode == 2) {
-                    while (k > 0) {                                        // entry 0 (z = -inf) ends the walk
-                        const float d = (float)zk - (float)osf, M = quad_zmargin((float)zk, vk, c0);
-                        bool stop = d < -M;                                // z < os for certain
-                        if (__builtin_expect(!stop && !(d > M), 0)) { DT_STAT(7); stop = exact_ztop(k, vk, sk) < osf; }
-                        if (stop) break;
-                        DT_STAT(2);
-                        --k;
-                        ring.template pop<BZ, true>(k, zk, sk, vk);
-                    }
-                } else {
-                    while (!(zk < osf)) {   // z[0] = -inf ends the walk
-                        DT_STAT(2);
-                        --k;
-                        ring.template pop<BZ>(k, zk, sk, vk);
-                    }
+                while (!(zk < osf)) {   // z[0] = -inf ends the walk
+                    DT_STAT(2);
+                    --k;
+                    ring.template pop<BZ>(k, zk, sk, vk);
                 }
                 out[i] = quad_val<R, BZ>(a, b, os0 + q - vk, sk);
                 dt_put<EPW>(ptr, i, vk);
@@ -384,8 +252,7 @@ static_assert(kDtCHC % 8 == 0 && kDtCH % 8 == 0, "int16 pointers and fp16 respon
 // RH: the responses are fp16 (PBD_CONV_MFMA_F16); a template parameter so that the default kernels carry none of it
 // PT: element type of the position planes (uint8_t when no map side exceeds 256, else int16_t)
 template <typename R, bool RH, typename PT, bool BZ>
-__global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 6 : 1)))
-void k_dt_rows(DpParams p)
+__global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
     constexpr int EPW = 4 / (int)sizeof(PT);
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
@@ -421,8 +288,7 @@ void k_dt_rows(DpParams p)
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
-                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) +
-                                         (PBD_DT_LANEMAJOR ? (size_t)lane * ((p.stk_row_off[wv + 1] - p.stk_row_off[wv]) >> 6) : (size_t)lane), job.ax, job.bx);
+                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane, job.ax, job.bx);
     const int N = active ? W : 0;
     if (N == 0) return;
     auto load = [&](int q0, R *buf) {
@@ -482,7 +348,7 @@ void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
 template <typename R, typename PT, bool BZ>
-__global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 6 : 1)))
+__global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? (sizeof(PT) == 1 ? 6 : 5) : 1)))
 void k_dt_cols(DpParams p)
 {
     constexpr int EPW = 4 / (int)sizeof(PT);
@@ -503,8 +369,7 @@ void k_dt_cols(DpParams p)
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
     DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
-                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) +
-                                         (PBD_DT_LANEMAJOR ? (size_t)lane * ((p.stk_col_off[wv + 1] - p.stk_col_off[wv]) >> 6) : (size_t)lane), job.ay, job.by);
+                                         ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane, job.ay, job.by);
     auto load = [&](int q0, R *buf) {
         if (sizeof(R) == 4 && q0 + kDtCHC <= H) {
             const float *srcf = reinterpret_cast<const float *>(tmpT);
