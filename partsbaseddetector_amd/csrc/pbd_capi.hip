@@ -736,8 +736,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         if (sizes.size() > 1) HIPCHK(h, C.fmap.upload(ids));
         if (fast5) {
             std::vector<int> uf0, uql;
-            const char *env_nw = getenv("PBD_CONV3_UNITS_NW");     // experiments: cut the units for another wave count
-            conv_units(C.nf, env_nw && atoi(env_nw) > 0 ? atoi(env_nw) : kConv3NW, uf0, uql);
+            conv_units(C.nf, kConv3NW, uf0, uql);
             C.nunits = (int)uf0.size();
             std::vector<int> uoff(C.nunits, 0);
             size_t tot = 0;

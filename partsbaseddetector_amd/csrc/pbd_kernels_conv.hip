@@ -8,14 +8,10 @@
 // the sign of an intermediate zero, which cannot reach the response: it starts at +0 and x + (+-0)
 // == x).  FMA mode fuses multiply and add (scores within 1e-4, not bit-identical).
 //
-// Mapping: one workgroup = one 256-cell tile (32 x 8, 16 x 16 or 8 x 32: the host covers each level with
-// the mix that wastes the fewest lanes) of one level of one frame.  The (TW+k-1) x (TH+k-1) x 32
-// channel input tile is staged once in LDS, re-laid out channel-planar so that a wave's lanes
-// (consecutive x) read consecutive LDS words; out-of-image cells are materialised with the
-// reference's constant border (0, but 1 for the last channel: :147-156).  Each thread owns one
-// output pixel and sweeps the filters in groups of 8; the 8 weights of a (channel, tap) are
-// wave-uniform and come through the scalar cache, so the inner loop is 16 VALU ops per LDS read.
-// Compiled with -ffp-contract=off.
+// Two kernels: k_conv3 (float, 5 x 5 filters -- every known model: strip-sequence tiles staged channel-planar in LDS,
+// weights through the scalar unit, packed multiply / add) and k_conv_generic (any filter size 1..7, T = float or double).
+// Out-of-image cells are materialised with the reference's constant border (0, but 1 for the last channel:
+// src/SpatialConvolutionEngine.cpp:147-156).  Compiled with -ffp-contract=off.
 #include "pbd_internal.h"
 
 #include <algorithm>
@@ -23,11 +19,8 @@
 
 namespace pbd {
 
-// Weights are read-only for the whole launch and every address is wave-uniform: reading them
-// through the constant address space lets the compiler keep them in SGPRs (s_load_dwordx8).
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef const v4f __attribute__((address_space(4))) cfloat4;
 
 // ------------------------------------------------------------------------------------------------------------------
 // The exact / FMA 5 x 5 convolution (k_conv3).
