@@ -183,9 +183,10 @@ def main():
     if args.warmup > 0:
         run(args.warmup)
     # Inside the timed region only the dominant kernel (the convolution: one launch per step) carries HIP events -- that is
-    # where `roofline` comes from.  Timing EVERY launch makes the runtime isolate each of the ~45 dispatches of a step
-    # (about 1 ms per step), so the full per-kernel table (`kernel_ms_per_step`, `roofline_all`) is taken from
-    # `profiled_steps` further steps run right after the timed region, and is not part of `value`.
+    # where `roofline` comes from.  Timing EVERY launch separates the ~45 dispatches of a step by about 9 us each
+    # (profiles/r03_trace_gaps.txt: 393 us of idle GPU time per step with per-kernel events, 18 us without), so the full
+    # per-kernel table (`kernel_ms_per_step`, `roofline_all`) is taken from `profiled_steps` further steps run right after
+    # the timed region, and is not part of `value`.
     if not args.no_profile:
         det.hd.profile(2)
     sync()
@@ -313,7 +314,29 @@ def main():
             oracle.detect(flat, frames[0])
             c1 = time.perf_counter() - t1
             oracle.set_num_threads(ncpu)
+            # the same sources at -O3, in a child interpreter (oracle.py's PBD_ORACLE_SO switch): SURVEY 8(d) "also -O3"
+            o3 = None
+            try:
+                import subprocess
+                so3 = os.path.join(ROOT, "oracle", "libpbd_oracle_o3.so")
+                subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), so3])
+                code = ("import sys, time, numpy as np; sys.path.insert(0, %r)\n"
+                        "from oracle import oracle; from partsbaseddetector_amd import synth\n"
+                        "from partsbaseddetector_amd.model import synthetic_person_model\n"
+                        "flat = synthetic_person_model().flatten(); oracle.set_num_threads(%d)\n"
+                        "fr = [synth.synthetic_frame(i + 1, %d, %d, 3) for i in range(%d)]\n"
+                        "oracle.detect(flat, fr[0]); t = time.perf_counter()\n"
+                        "for f in fr: oracle.detect(flat, f)\n"
+                        "print(len(fr) / (time.perf_counter() - t))\n") % (ROOT, ncpu, rows, cols, min(nf, 4))
+                r3 = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                                    env=dict(os.environ, PBD_ORACLE_SO=so3))
+                o3 = {"value": round(float(r3.stdout.strip().splitlines()[-1]), 4), "unit": "detections/s", "cores": ncpu,
+                      "flags": "-O3 -ftree-vectorize -msse4.1 -fopenmp -ffp-contract=off", "sample": f"{min(nf, 4)} frames"}
+            except Exception as e:          # the baseline is context, never a reason to lose the bench line
+                o3 = {"error": str(e)[:200]}
             cpu = {"value": round(nf / cdt, 4), "unit": "detections/s", "cores": oracle.num_threads(), "kind": "port",
+                   "flags": "-O2 -ftree-vectorize -msse4.1 -fopenmp -ffp-contract=off (the reference's RelWithDebInfo, CMakeLists.txt:56-61,74-81)",
+                   "O3": o3,
                    "sample": f"{nf} of the same {cols}x{rows} frames, full path, OpenMP at the reference's 5 sites",
                    "stage_ms_per_frame": {k: round(v, 2) for k, v in stage.items()},
                    "single_thread": {"value": round(1.0 / c1, 4), "unit": "detections/s", "cores": 1, "sample": "1 frame"}}
@@ -408,9 +431,11 @@ def main():
                                    "overlap": "the collective of batch k runs under the kernels of batch k+1 (begin / finish one step apart)"} if gatherer else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": stage_ms,
             "kernel_timing": ({"roofline": "k_conv: HIP events on its launch inside the timed region (avg of %d launches)" % (prof_timed.get("k_conv", (0, 0))[1]),
-                               "kernel_ms_per_step": "HIP events on every launch, %d further steps right after the timed region (%.3f ms per step there: "
-                                                     "timing every dispatch costs about 1 ms per step, so it is kept out of `value`)" % (profiled_steps, dt_prof / psteps * 1e3),
-                               "step_minus_kernels_ms": round(dt / args.steps * 1e3 - sum(stage_ms.values()), 3)} if not args.no_profile else None),
+                               "kernel_ms_per_step": "HIP events on every launch, %d further steps right after the timed region (%.3f ms per step there)" % (profiled_steps, dt_prof / psteps * 1e3),
+                               "step_minus_kernels_ms": round(dt / args.steps * 1e3 - sum(stage_ms.values()), 3),
+                               "note": "step_minus_kernels_ms compares back-to-back execution with kernels timed in isolation (each dispatch then starts on an idle chip "
+                                       "and runs 1-2 % faster), so it overstates the idle time; the rocprofv3 kernel trace of the timed configuration shows 18 us of idle "
+                                       "GPU time per 64-frame step (profiles/r03_trace_gaps.txt)"} if not args.no_profile else None),
             "roofline_all": roof_all,
             ("fast_mode" if args.conv_mode == "exact" else "exact_mode"): other_mode, "agreement": agreement,
             "host_input": host_input,
