@@ -166,17 +166,31 @@ __device__ __forceinline__ void conv_tile3(const ConvParams &p, const float *__r
         // or the next channel's first four; the 5 x QL weights of the next tap row) are issued before the packed operations
         // of the stage, into registers the stage does not touch -- a wave never waits for its own reads.
         float Ft[P + K - 1][K];
-        v2f Wt[2][K][QH];              // SGPRs: tap row in use | tap row being fetched
-        auto load_row = [&](int c, int rr) {
-            const float *sp = sp0 + c * PLANE + rr * PW;
+        // SGPRs.  Taps 0..2 of a tap row are fetched one stage ahead (two buffers); taps 3..4 at the start of the stage that
+        // uses them, three taps (about 100 packed operations per wave, four waves interleaved) before their first use -- 64
+        // scalar registers instead of 80, which is what lets the loop keep its other scalars out of spill lanes
+        constexpr int KA = 3;
+        v2f Wa[2][KA][QH], Wb[K - KA][QH];
+        // LDS addressing: ONE running base (the lane's window in the plane of the pair's first channel, advanced by two planes
+        // per iteration); everything else is an immediate offset -- the planes span 76 KB, more than an offset field reaches,
+        // and per-channel bases computed from the channel index cost a dozen address registers the loop does not have
+        const float *spc = sp0;
+        auto load_row = [&](const float *base, int rr) {
+            const float *sp = base + rr * PW;
 #pragma unroll
             for (int j = 0; j < K; ++j) Ft[rr][j] = sp[j];
         };
-        auto load_w = [&](int buf, int c, int i) {
+        auto load_w = [&](int buf, int c, int i) {          // taps 0..2 of tap row (c, i): for the NEXT stage
 #pragma unroll
-            for (int j = 0; j < K; ++j)
+            for (int j = 0; j < KA; ++j)
 #pragma unroll
-                for (int q = 0; q < QH; ++q) Wt[buf][j][q] = *(cfloat2 *)(wc + ((c * K + i) * K + j) * QL + 2 * q);
+                for (int q = 0; q < QH; ++q) Wa[buf][j][q] = *(cfloat2 *)(wc + ((c * K + i) * K + j) * QL + 2 * q);
+        };
+        auto load_wb = [&](int c, int i) {                  // taps 3..4 of tap row (c, i): for THIS stage
+#pragma unroll
+            for (int j = KA; j < K; ++j)
+#pragma unroll
+                for (int q = 0; q < QH; ++q) Wb[j - KA][q] = *(cfloat2 *)(wc + ((c * K + i) * K + j) * QL + 2 * q);
         };
         v2f s[P][QH];
         auto zero_s = [&]() {
@@ -196,33 +210,28 @@ __device__ __forceinline__ void conv_tile3(const ConvParams &p, const float *__r
             for (int j = 0; j < K; ++j) {
                 v2f w[QH];
 #pragma unroll
-                for (int q = 0; q < QH; ++q) w[q] = Wt[wbi][j][q];
-                // RB rows at a time: at least four products, then their additions -- an addition issues >= 16 cycles after its
-                // product (with three pairs per row a row-by-row order would put it 12 cycles after, and stall)
-                constexpr int RB = QH >= 4 ? 1 : QH == 3 ? 2 : QH == 2 ? 2 : 4;
+                for (int q = 0; q < QH; ++q) w[q] = j < KA ? Wa[wbi][j][q] : Wb[j - KA][q];
+                // products, then their additions, PB pairs at a time: with four waves on a SIMD the other waves' instructions
+                // sit between a product and its addition, so two pairs are enough distance -- and two pairs of temporaries
+                // (not four) keep the loop inside 128 registers without a spill
+                constexpr int PB = 2;
+                const bool first = (i == 0 && j == 0);
+                const v2f zero2 = v2f{0.0f, 0.0f};
 #pragma unroll
-                for (int p0 = 0; p0 < P; p0 += RB) {
-                    const bool first = (i == 0 && j == 0);
-                    const v2f zero2 = v2f{0.0f, 0.0f};
+                for (int pp = 0; pp < P; ++pp) {
+                    const v2f f = v2f{Ft[pp + i][j], Ft[pp + i][j]};
                     if (FMA) {
 #pragma unroll
-                        for (int pr = 0; pr < RB; ++pr) {
-                            const v2f f = v2f{Ft[p0 + pr + i][j], Ft[p0 + pr + i][j]};
-#pragma unroll
-                            for (int q = 0; q < QH; ++q) s[p0 + pr][q] = __builtin_elementwise_fma(w[q], f, first ? zero2 : s[p0 + pr][q]);
-                        }
+                        for (int q = 0; q < QH; ++q) s[pp][q] = __builtin_elementwise_fma(w[q], f, first ? zero2 : s[pp][q]);
                     } else {
-                        v2f tq[RB][QH];
 #pragma unroll
-                        for (int pr = 0; pr < RB; ++pr) {
-                            const v2f f = v2f{Ft[p0 + pr + i][j], Ft[p0 + pr + i][j]};
+                        for (int q0 = 0; q0 < QH; q0 += PB) {
+                            v2f tq[PB];
 #pragma unroll
-                            for (int q = 0; q < QH; ++q) tq[pr][q] = w[q] * f;
+                            for (int q = q0; q < q0 + PB && q < QH; ++q) tq[q - q0] = w[q] * f;
+#pragma unroll
+                            for (int q = q0; q < q0 + PB && q < QH; ++q) s[pp][q] = first ? tq[q - q0] : s[pp][q] + tq[q - q0];
                         }
-#pragma unroll
-                        for (int pr = 0; pr < RB; ++pr)
-#pragma unroll
-                            for (int q = 0; q < QH; ++q) s[p0 + pr][q] = first ? tq[pr][q] : s[p0 + pr][q] + tq[pr][q];
                     }
                 }
             }
@@ -255,19 +264,19 @@ __device__ __forceinline__ void conv_tile3(const ConvParams &p, const float *__r
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
 #pragma unroll
-        for (int rr = 0; rr < P; ++rr) load_row(0, rr);
+        for (int rr = 0; rr < P; ++rr) load_row(spc, rr);
         load_w(0, 0, 0);
         zero_s();                      // defined values for the first pin; every channel starts its own sum
         // one channel: rows 4..7 arrive during stages 0..3, the next channel's rows 0..3 during stage 4 (rows 0..3 are dead
         // by then); the tap rows alternate between the two weight buffers, so two channels make the pattern repeat.  Nothing
         // is conditional (the last iteration re-reads channel 31)
-#define PBD_CHANNEL3(c, cn, B0, B1)                                                                                                \
+#define PBD_CHANNEL3(c, cn, SPC, SPN, B0, B1)                                                                                      \
     do {                                                                                                                          \
-        PBD_STAGE3(load_row((c), 4); load_w(B1, (c), 1), B0, 0);                                                                  \
-        PBD_STAGE3(load_row((c), 5); load_w(B0, (c), 2), B1, 1);                                                                  \
-        PBD_STAGE3(load_row((c), 6); load_w(B1, (c), 3), B0, 2);                                                                  \
-        PBD_STAGE3(load_row((c), 7); load_w(B0, (c), 4), B1, 3);                                                                  \
-        PBD_STAGE3(load_row((cn), 0); load_row((cn), 1); load_row((cn), 2); load_row((cn), 3); load_w(B1, (cn), 0), B0, 4);       \
+        PBD_STAGE3(load_row((SPC), 4); load_wb((c), 0); load_w(B1, (c), 1), B0, 0);                                               \
+        PBD_STAGE3(load_row((SPC), 5); load_wb((c), 1); load_w(B0, (c), 2), B1, 1);                                               \
+        PBD_STAGE3(load_row((SPC), 6); load_wb((c), 2); load_w(B1, (c), 3), B0, 2);                                               \
+        PBD_STAGE3(load_row((SPC), 7); load_wb((c), 3); load_w(B0, (c), 4), B1, 3);                                               \
+        PBD_STAGE3(load_row((SPN), 0); load_row((SPN), 1); load_row((SPN), 2); load_row((SPN), 3); load_wb((c), 4); load_w(B1, (cn), 0), B0, 4); \
         add_s();                                                                                                                  \
     } while (0)
         // channel 31 is zero over the whole patch of an interior tile (skip31): its sum is +-0 and r + (+-0) == r, so those
@@ -277,10 +286,12 @@ __device__ __forceinline__ void conv_tile3(const ConvParams &p, const float *__r
 #pragma clang loop unroll(disable)
         for (int c = 0; c < cpairs; c += 2) {
             const int c2 = min(c + 2, 31);
-            PBD_CHANNEL3(c, c + 1, 0, 1);
-            PBD_CHANNEL3(c + 1, c2, 1, 0);
+            const float *spn = spc + (c2 - c) * PLANE;       // c2 - c: 2, or 1 in the last iteration (wave-uniform)
+            PBD_CHANNEL3(c, c + 1, spc, spc + PLANE, 0, 1);
+            PBD_CHANNEL3(c + 1, c2, spc + PLANE, spn, 1, 0);
+            spc += 2 * PLANE;
         }
-        if (skip31) PBD_CHANNEL3(30, 31, 0, 1);
+        if (skip31) PBD_CHANNEL3(30, 31, spc, spc + PLANE, 0, 1);
 #undef PBD_CHANNEL3
 #undef PBD_STAGE3
 #undef PBD_PIN3

@@ -11,7 +11,7 @@ import json
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-names = {"k_resize4": "k_resize", "k_hog_tile": "k_hog_hist", "k_hog_grad4": "k_hog_hist", "k_hog_grad": "k_hog_hist", "k_conv_mfma<": "k_conv_mfma", "k_conv<": "k_conv", "k_dt_rows": "k_dt_rows", "k_dt_cols": "k_dt_cols", "k_dp_combine": "k_dp_combine",
+names = {"k_resize4": "k_resize", "k_hog_tile": "k_hog_hist", "k_hog_grad4": "k_hog_hist", "k_hog_grad": "k_hog_hist", "k_conv_mfma<": "k_conv_mfma", "k_conv<": "k_conv", "k_conv3<": "k_conv", "k_dt_rows": "k_dt_rows", "k_dt_cols": "k_dt_cols", "k_dp_combine": "k_dp_combine",
          "k_hog_hist": "k_hog_hist", "k_hog_feat": "k_hog_feat", "k_resize": "k_resize", "k_pyrdown": "k_pyrdown", "k_dp_root": "k_dp_root"}
 acc = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
 import os
