@@ -227,7 +227,9 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 
 }
 
 template <int K, bool F16>
-__global__ __launch_bounds__(256, F16 ? 4 : 3) void k_conv_mfma(ConvParams p, const u32x4 *__restrict__ wfrag,
+// two workgroups of four waves per CU (LDS: 62 KB each in bf16 mode): two waves per SIMD is what the kernel gets, so that is
+// what it asks for -- a request of three made the compiler squeeze to 168 registers it could not reach (220) for nothing
+__global__ __launch_bounds__(256, F16 ? 4 : 2) void k_conv_mfma(ConvParams p, const u32x4 *__restrict__ wfrag,
                                                                       const float *__restrict__ featp, float *__restrict__ respp)
 {
     __shared__ __attribute__((aligned(16))) unsigned char sm_f[433 * MfmaRec<F16>::kBytes];
