@@ -902,7 +902,7 @@ int build_model(pbd_handle *h, const pbd_model *m)
             }
         }
     }
-    if (h->max_parts > 80) return fail(h, PBD_ERR_UNSUPPORTED, "%d parts per component (max 80)", h->max_parts);
+    if (h->max_parts > kWalkMaxParts) return fail(h, PBD_ERR_UNSUPPORTED, "%d parts per component (max %d)", h->max_parts, kWalkMaxParts);
     h->NS = NS;
 
     // children (descending index) per part
@@ -1122,11 +1122,8 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     for (int k = 0; k < 3; ++k) cp.nshaped[k] = P.nshaped[k];
     cp.segtiles = nullptr; cp.nsegtiles = 0;
     if (!h->f64 && h->cfg.conv_mode != PBD_CONV_MFMA && h->cfg.conv_mode != PBD_CONV_MFMA_F16) {
-        auto it = P.segtiles.find(nb);
-        if (it == P.segtiles.end()) {            // first launch of this many frames on this plan (alloc_conv built it)
-            return;
-        }
-        cp.segtiles = it->second.d; cp.nsegtiles = (int)it->second.n;
+        const auto it = P.segtiles.find(nb);     // built by ensure_seg_tiles before the first launch of this many frames
+        if (it != P.segtiles.end()) { cp.segtiles = it->second.d; cp.nsegtiles = (int)it->second.n; }
     }
     cp.F = h->F; cp.frame0 = f0;
     cp.cell_per_frame = P.cell_per_frame;

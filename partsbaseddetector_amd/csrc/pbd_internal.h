@@ -111,6 +111,7 @@ struct PartWalk {             // argmin tree walk, one per part of a component
 };
 
 constexpr int kMaxMix = 8;
+constexpr int kWalkMaxParts = 160;   // parts per component the back-tracking walk holds in LDS (Face_68parts: 68, Person_26parts: 26)
 // bytes of one spilled PAIR of envelope-stack entries {T sa, sb, za; unsigned vv;} (natural alignment of T)
 constexpr size_t kStkPairF32 = 16, kStkPairF64 = 32;
 constexpr int kConvTW = 32, kConvTH = 8, kConvQ = 8;

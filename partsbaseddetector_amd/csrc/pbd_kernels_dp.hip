@@ -836,8 +836,7 @@ template <> __device__ __forceinline__ int round_mul<double>(int a, double s) { 
 // walk: one thread per candidate follows Ix/Iy/Ik from the root (src/DynamicProgram.cpp:218-244).  The number of
 // candidates is read from word 0 of the payload (the host never needs it to launch this); the grid strides over
 // min(found, capacity) records.  The positions and mixtures of the parts already visited sit in LDS (x | y << 16 and the
-// mixture, one column per thread: 45 KB) -- not in per-thread scratch.
-constexpr int kWalkMaxParts = 80;
+// mixture, one column per thread: 51 KB for up to kWalkMaxParts = 160 parts) -- not in per-thread scratch.
 template <typename R, typename PT>
 __global__ __launch_bounds__(64) void k_argmin_walk(ArgminParams p)
 {
