@@ -119,7 +119,7 @@ def main():
     model = synthetic_person_model()
     flat = model.flatten()
     B, rows, cols, cn = args.batch, args.rows, args.cols, 3
-    cap = 1 << 16
+    cap = max(1 << 16, int(B * rows * cols / (480 * 640) * 1024))      # candidate capacity: ~100 per VGA frame at the synthetic threshold, 10x head-room
     det = PartsBasedDetector(device=local_rank, conv_mode={"exact": _lib.CONV_EXACT, "fma": _lib.CONV_FMA, "mfma": _lib.CONV_MFMA, "mfma_f16": _lib.CONV_MFMA_F16}[args.conv_mode],
                              max_batch=B, max_candidates=cap)
     det.distributeModel(model)
