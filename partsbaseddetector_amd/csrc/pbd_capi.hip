@@ -216,6 +216,8 @@ struct pbd_handle {
         DevBuf wts3;
         DevTable<int> unit_f0, unit_ql, unit_woff;
         int nunits = 0;
+        DevTable<float> c31tab;      // [81][c31stride]: see pbd_kernels_conv.hip (channel 31)
+        int c31stride = 0;
     };
     std::vector<ConvClass> conv_classes;
     DevBuf d_wrec;                   // bf16 hi/lo weight records of the matrix-core path
@@ -707,7 +709,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         std::vector<pbd_handle::ConvClass> classes;
         DevBuf wrec;
         bool keep = false;
-        ~NewBank() { if (!keep) { for (auto &c : classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); } wrec.release(); } }
+        ~NewBank() { if (!keep) { for (auto &c : classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); c.c31tab.release(); } wrec.release(); } }
     } nb;
     nb.classes.assign(sizes.size(), pbd_handle::ConvClass{});
     for (size_t ci = 0; ci < sizes.size(); ++ci) {
@@ -749,6 +751,26 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
                         for (int c = 0; c < 32; ++c) w3[uoff[u] + ((size_t)c * KK + t) * uql[u] + q] = (float)src[(size_t)t * 32 + c];
                 }
             HIPCHK(h, C.unit_woff.upload(uoff));
+            // channel 31 of a window that leaves the image: the reference's sum over the out-of-image taps (border value 1,
+            // src/SpatialConvolutionEngine.cpp:147-156) in its tap order (raster, zero weights skipped: src/filter.cpp:3818-3856,
+            // 3916-3922), for every combination of rows / columns outside at the top, bottom, left and right (0..2 each)
+            C.c31stride = (C.nf + 15) & ~7;                     // a unit's 8 consecutive entries stay inside the row
+            std::vector<float> tab((size_t)81 * C.c31stride, 0.0f);
+            for (int cs = 0; cs < 81; ++cs) {
+                const int right = cs % 3, left = cs / 3 % 3, bot = cs / 9 % 3, top = cs / 27;
+                for (int fl = 0; fl < C.nf; ++fl) {
+                    const R *src = static_cast<const R *>(filters[ids[fl]]);
+                    float sum = 0.0f;
+                    for (int i = 0; i < 5; ++i)
+                        for (int j = 0; j < 5; ++j) {
+                            if (!(i < top || i > 4 - bot || j < left || j > 4 - right)) continue;
+                            const float w = (float)src[(size_t)(i * 5 + j) * 32 + 31];
+                            if (w != 0.0f) sum = sum + w;
+                        }
+                    tab[(size_t)cs * C.c31stride + fl] = sum;
+                }
+            }
+            HIPCHK(h, C.c31tab.upload(tab));
             HIPCHK(h, C.wts3.ensure(w3.size() * sizeof(float)));
             HIPCHK(h, hipMemcpy(C.wts3.p, w3.data(), w3.size() * sizeof(float), hipMemcpyHostToDevice));
             HIPCHK(h, C.unit_f0.upload(uf0));
@@ -792,7 +814,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
         HIPCHK(h, hipMemcpy(nb.wrec.p, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
     }
     // commit
-    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); }
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); c.c31tab.release(); }
     h->conv_classes.swap(nb.classes);
     nb.classes.clear();
     if (mfma) { h->d_wrec.release(); h->d_wrec = nb.wrec; nb.wrec = DevBuf{}; }
@@ -1139,6 +1161,7 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
         cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
         cp.wts3 = C.wts3.p;
         cp.unit_f0 = C.unit_f0.d; cp.unit_ql = C.unit_ql.d; cp.unit_woff = C.unit_woff.d; cp.nunits = C.nunits;
+        cp.c31tab = C.c31tab.d; cp.c31stride = C.c31stride;
         cp.units_per_block = wgs >= 1024 ? std::max(C.nunits, 1) : std::max(1, (int)((long long)C.nunits * wgs / 1024));
         if (h->cfg.conv_mode == PBD_CONV_MFMA || h->cfg.conv_mode == PBD_CONV_MFMA_F16)
             launch_conv_mfma(cp, h->d_wrec.p, h->cfg.conv_mode == PBD_CONV_MFMA_F16, nb, st);
@@ -1548,7 +1571,7 @@ void pbd_destroy(pbd_handle *h)
                       &h->rooti, &h->tmp, &h->dt, &h->IxRaw, &h->IyRaw, &h->stk, &h->find_blk,
                       &h->scales_tmp})
         b->release();
-    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); }
+    for (auto &c : h->conv_classes) { c.wts.release(); c.fmap.release(); c.wts3.release(); c.unit_f0.release(); c.unit_ql.release(); c.unit_woff.release(); c.c31tab.release(); }
     h->d_wrec.release(); h->d_biasw.release(); h->d_coord.release(); h->d_walk_off.release();
     h->d_rjobs.release(); h->d_walk.release();
     for (auto &g : h->groups) { g.d_jobs.release(); g.d_childs.release(); g.d_cjobs.release(); g.d_sjobs.release(); }

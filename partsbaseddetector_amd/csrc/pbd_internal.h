@@ -171,6 +171,8 @@ struct ConvParams {
     const int *unit_woff;         // float offset of a unit's weights in wts3
     int nunits, units_per_block;
     int c31_zero;                 // the features come from this library's HOG: channel 31 is 0 in every cell of the image
+    const float *c31tab;          // k_conv3: [81 border cases][c31stride] ordered sums of the out-of-image taps' channel-31 weights
+    int c31stride;
     int frame0;
     long long cell_per_frame;
     const void *feat;             // R [frames][cell_per_frame*32]

@@ -87,17 +87,22 @@ __device__ __forceinline__ void conv_tile3(const ConvParams &p, const float *__r
         G.nlanes = lb;
         return G;
     };
-    bool skip31 = !FMA && p.c31_zero;
+    // Channel 31.  This library's HOG writes +0 there in every cell, and the convolution's border value for that channel is
+    // 1 (src/SpatialConvolutionEngine.cpp:147-156): a tap contributes w * 1 = w when it falls outside the image and +-0 inside,
+    // so the channel's sum is the ORDERED sum of the weights of the out-of-image taps -- a function of how many rows / columns
+    // of the window stick out on each side (81 cases, tabulated per filter on the host in the reference's tap order) -- and it
+    // is the LAST term added to the response (:85-93).  Exact mode therefore runs 31 channels and, for lanes whose window
+    // leaves the image, adds the tabulated sum afterwards: the same rounding sequence, 1/32 less work.  (With features the
+    // caller supplied, c31_zero is false and the channel is computed like the others; so it is in FMA mode, kept literal.)
+    const bool skip31 = !FMA && p.c31_zero;
+    bool interior = true;                                    // every window of the tile lies inside its level
     const float *sp0;
     const Geom G = load_geom();
     {
     const int lane0 = t & 63;
-    // HOG channel 31 is 0 inside the image (1 only in the constant border): a tile all of whose patches lie inside their
-    // levels skips that channel (exact mode only -- a fused multiply-add of zeros changes nothing either, but the FMA
-    // mode is kept literal)
 #pragma unroll
     for (int k = 0; k < kConvMaxSeg; ++k)
-        if (k < G.nseg) skip31 = skip31 && G.x0[k] >= a && G.x0[k] + G.len[k] + a <= G.W[k] && G.y0[k] >= a && G.y0[k] + P + a <= G.H[k];
+        if (k < G.nseg) interior = interior && G.x0[k] >= a && G.x0[k] + G.len[k] + a <= G.W[k] && G.y0[k] >= a && G.y0[k] + P + a <= G.H[k];
     {   // the lane's LDS window
         const int k = (lane0 >= G.lb[1] && G.nseg > 1 ? 1 : 0) + (lane0 >= G.lb[2] && G.nseg > 2 ? 1 : 0);
         sp0 = sm + (k == 0 ? G.cb[0] - G.lb[0] : k == 1 ? G.cb[1] - G.lb[1] : G.cb[2] - G.lb[2]) + lane0;
@@ -279,8 +284,7 @@ __device__ __forceinline__ void conv_tile3(const ConvParams &p, const float *__r
         PBD_STAGE3(load_row((SPN), 0); load_row((SPN), 1); load_row((SPN), 2); load_row((SPN), 3); load_wb((c), 4); load_w(B1, (cn), 0), B0, 4); \
         add_s();                                                                                                                  \
     } while (0)
-        // channel 31 is zero over the whole patch of an interior tile (skip31): its sum is +-0 and r + (+-0) == r, so those
-        // tiles run 15 pairs and channel 30 alone -- as an epilogue, not as a break inside the loop body, which stays one
+        // skip31: 15 pairs and channel 30 alone -- as an epilogue, not as a break inside the loop body, which stays one
         // basic block
         const int cpairs = skip31 ? 30 : 32;
 #pragma clang loop unroll(disable)
@@ -306,6 +310,21 @@ __device__ __forceinline__ void conv_tile3(const ConvParams &p, const float *__r
         const size_t HW = (size_t)H * W;
         float *respg = respp + (size_t)cell * p.F + (size_t)y * W + x;
         const bool live = ln < g[7];
+        if (skip31 && !interior && live) {
+            // channel 31's term for the windows that leave the image: rows / columns outside on each side, clipped to 0..2
+            const int left = min(max(a - x, 0), a), right = min(max(x + a - (W - 1), 0), a);
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                const int yy = y + pp;
+                const int top = min(max(a - yy, 0), a), bot = min(max(yy + a - (H - 1), 0), a);
+                const int cs = ((top * 3 + bot) * 3 + left) * 3 + right;
+                if (cs != 0 && yy < H) {
+                    const float *tab = p.c31tab + (size_t)cs * p.c31stride + f0;
+#pragma unroll
+                    for (int q = 0; q < QL; ++q) r[pp][q / 2][q & 1] += tab[q];
+                }
+            }
+        }
         if (f0 + QL <= p.nf && p.fmap == nullptr) {
             // a full unit stores without per-filter branches: one block of QL independent stores per row
             float *rg = respg + (size_t)f0 * HW;

@@ -785,3 +785,34 @@ def test_non_finite_pixels_are_refused(det_mod, IT):
     again = det.detect(im)                                   # the handle is still usable
     assert [(c.level, c.root, c.score()) for c in again] == [(c.level, c.root, c.score()) for c in good]
     det.hd.close()
+
+
+def test_fused_path_responses_every_level(det_mod, oracle):
+    """The fused detect path runs the exact convolution WITHOUT channel 31 (this library's HOG writes +0 there) and adds, for
+    windows that leave the image, the tabulated ordered sum of the out-of-image taps' channel-31 weights (border value 1:
+    src/SpatialConvolutionEngine.cpp:147-156) as the last term.  Every response of every level -- down to maps of 5 x 4 cells,
+    where a window sticks out on both sides at once -- must equal the reference-order convolution of the same features."""
+    from partsbaseddetector_amd import _lib
+    model = M.synthetic_person_model(thresh=1e9)            # no candidates: only the staged responses matter
+    flat = model.flatten()
+    for shape in ((120, 161), (97, 83)):
+        im = synth.synthetic_frame(77, shape[0], shape[1], 3)
+        det = det_mod.PartsBasedDetector(device=0)
+        det.distributeModel(model)
+        assert det.detect(im) == []
+        plan = det.hd.plan(*shape)
+        feats, _ = oracle.features_pyramid(flat, im)
+        checked = 0
+        for l in range(plan["nlevels"]):
+            h, w = int(plan["feat_rows"][l]), int(plan["feat_cols"][l])
+            if h * w == 0:
+                continue
+            got = det.hd.get_stage(_lib.STAGE_RESPONSES, 0, l, h, w)
+            f = det.hd.get_stage(_lib.STAGE_FEATURES, 0, l, h, w)
+            assert np.array_equal(f.view(np.uint32), np.ascontiguousarray(feats[l], np.float32).reshape(f.shape).view(np.uint32))
+            assert not f.reshape(h, w, 32)[:, :, 31].any()
+            want = oracle.responses(flat, f)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (shape, l, h, w, np.abs(got - want).max())
+            checked += 1
+        assert checked >= 10 and min(int(plan["feat_rows"][-1]), int(plan["feat_cols"][-1])) <= 5
+        det.hd.close()
