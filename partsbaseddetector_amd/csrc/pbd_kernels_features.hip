@@ -847,8 +847,16 @@ __global__ __launch_bounds__(256) void k_hog_feat(HogParams p)
     __shared__ long long s_off[PBD_MAX_LEVELS];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int l = find_level_blk<2>(p.lv, 0, p.nlevels, idx, s_off);
-    if (idx >= p.cell_per_frame) return;
+    // float: the 32 values of a cell leave through LDS so that a store instruction writes 1 KB of consecutive addresses (a
+    // block's 256 cells are consecutive in the feature buffer); written straight from the registers every 16-byte store of a
+    // wave touched 64 different 128-byte lines
+    constexpr bool VIA_LDS = sizeof(R) == 4;
+    constexpr int kPitch = 36;                       // floats per cell in LDS: 16-byte aligned, 4 banks apart
+    __shared__ __attribute__((aligned(16))) float tile[VIA_LDS ? 256 * kPitch : 4];
+    const bool valid = idx < p.cell_per_frame;
+    if (!VIA_LDS && !valid) return;
     const int frame = p.frame0 + blockIdx.y;
+    if (valid) {
     const LevelDesc d = p.lv[l];
     const int local = (int)(idx - d.cell_off);
     const int y = local / d.cols, x = local - y * d.cols;
@@ -890,11 +898,32 @@ __global__ __launch_bounds__(256) void k_hog_feat(HogParams p)
     out[29] = (R)(0.2357 * (double)t3);
     out[30] = (R)(0.2357 * (double)t4);
     out[31] = (R)0;
-    R *dst = static_cast<R *>(p.feat) + ((size_t)frame * p.cell_per_frame + idx) * 32;
     typedef R rv4 __attribute__((ext_vector_type(4)));
+    if constexpr (VIA_LDS) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) reinterpret_cast<rv4 *>(dst)[i] = rv4{out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]};
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<rv4 *>(tile + threadIdx.x * kPitch + 4 * i) = rv4{out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]};
+    } else {
+        R *dst = static_cast<R *>(p.feat) + ((size_t)frame * p.cell_per_frame + idx) * 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) reinterpret_cast<rv4 *>(dst)[i] = rv4{out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]};
+    }
+    }
+    if constexpr (VIA_LDS) {
+        __syncthreads();
+        const long long idx0 = (long long)blockIdx.x * blockDim.x;
+        const int nq = (int)min((long long)256, p.cell_per_frame - idx0) * 8;          // 16-byte pieces of this block
+        typedef float fv4 __attribute__((ext_vector_type(4)));
+        fv4 *dst = reinterpret_cast<fv4 *>(static_cast<float *>(p.feat) + ((size_t)frame * p.cell_per_frame + idx0) * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = (int)threadIdx.x + 256 * i;
+            if (j < nq) dst[j] = *reinterpret_cast<const fv4 *>(tile + (j >> 3) * kPitch + (j & 7) * 4);
+        }
+    }
 }
+
+
 
 void launch_hog_feat(const HogParams &p, int nframes, bool f64, hipStream_t s)
 {
