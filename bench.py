@@ -267,7 +267,8 @@ def main():
             avg_s = ms / n * 1e-3
             by = work[k]["bytes"] / per_step
             tr = traffic_tab.get(k, {}).get("hbm_bytes_per_step")
-            entry = {"kernel": k, "avg_launch_ms": round(ms / n, 4), "launches_per_step": per_step,
+            symbol = {"k_conv": "k_conv_mfma" if args.conv_mode in ("mfma", "mfma_f16") else "k_conv3", "k_hog_hist": "k_hog_tile"}.get(k, k)
+            entry = {"kernel": k, "symbol": symbol, "avg_launch_ms": round(ms / n, 4), "launches_per_step": per_step,
                      "algorithmic_bytes_per_launch": int(by), "traffic": (tr / per_step) if tr else None}
             if k == "k_conv":
                 fl = work[k]["flop"] / per_step
