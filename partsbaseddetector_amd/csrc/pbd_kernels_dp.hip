@@ -176,22 +176,6 @@ template <typename R, bool AUX, bool BZ, int CH, int EPW, class LoadChunk, class
 __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store,
                                           AuxChunk aux)
 {
-#if defined(PBD_DT_EXP) && (PBD_DT_EXP & 64)
-    {   // TIMING PROBE: the passes' input / output skeleton alone (no envelope)
-        R c0[CH];
-        int a0[CH / EPW];
-        for (int q0 = 0; q0 < N; q0 += CH) {
-            load(q0, c0);
-            int pp[CH / EPW];
-#pragma unroll
-            for (int i = 0; i < CH / EPW; ++i) { pp[i] = 0; a0[i] = 0; }
-#pragma unroll
-            for (int i = 0; i < CH; ++i) dt_put<EPW>(pp, i, (q0 + i) & 255);
-            store(q0, c0, pp, a0);
-        }
-        return;
-    }
-#endif
     R cur[CH], nxt[CH];
     load(0, cur);
     int k = 0, vk = 0;
@@ -203,15 +187,7 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
         for (int i = 0; i < CH; ++i) {
             const int q = q0 + i;
             if (q >= 1 && q < N) {
-#if defined(PBD_DT_EXP) && (PBD_DT_EXP & 8)
-                const R sq = (R)(-(float)(q * q));                 // TIMING PROBE: every element pops the whole stack but entry 0
-#elif defined(PBD_DT_EXP) && (PBD_DT_EXP & 16)
-                const R sq = (R)((float)(q * q));                  // TIMING PROBE: no element is ever popped (the stack grows to N)
-#elif defined(PBD_DT_EXP) && (PBD_DT_EXP & 32)
-                const R sq = (R)((float)((q & 7) * (q & 7)) - (float)(q >> 3));   // TIMING PROBE: runs of 8 kept, popped by the next run
-#else
                 const R sq = cur[i];
-#endif
                 DT_STAT(0);
                 R s = quad_isect<R, BZ>(a, b, vk, q, sk, sq);
                 while (s <= zk && k > 0) {
@@ -249,11 +225,7 @@ __device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, Dt
             if (q < N) {
                 const R osf = (R)(os0 + q);
                 DT_STAT(5);
-#if defined(PBD_DT_EXP)
-                while (!(zk < osf) && k > 0) {
-#else
                 while (!(zk < osf)) {   // z[0] = -inf ends the walk
-#endif
                     DT_STAT(2);
                     --k;
                     ring.template pop<BZ>(k, zk, sk, vk);
@@ -752,11 +724,7 @@ __device__ __forceinline__ int find_hits(const ArgminParams &p, long long base, 
 #pragma unroll
     for (int e = 0; e < kFindEPT; ++e) {
         const long long o = base + e;
-#if defined(PBD_DT_EXP)
-        hit[e] = false;                                       // timing probes: no candidates
-#else
-        hit[e] = o < p.ntotal && rv[o] > (R)p.thresh;
-#endif       // NaN compares false, as in the reference's `rootv > thresh` mask
+        hit[e] = o < p.ntotal && rv[o] > (R)p.thresh;       // NaN compares false, as in the reference's `rootv > thresh` mask
         c += hit[e] ? 1 : 0;
     }
     return c;
