@@ -117,6 +117,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     model = synthetic_person_model()
+    if os.environ.get("PBD_BENCH_THRESH"):          # timing probes whose scores are deliberately wrong (tools/ab.sh): no candidates
+        model.thresh = float(os.environ["PBD_BENCH_THRESH"])
     flat = model.flatten()
     B, rows, cols, cn = args.batch, args.rows, args.cols, 3
     cap = max(1 << 16, int(B * rows * cols / (480 * 640) * 1024))      # candidate capacity: ~100 per VGA frame at the synthetic threshold, 10x head-room

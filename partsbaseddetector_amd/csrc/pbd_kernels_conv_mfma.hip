@@ -44,13 +44,14 @@ template <bool F16> struct MfmaRec { static constexpr int kBytes = F16 ? kMfmaRe
 
 template <int K, bool F16, int S>
 __device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 *__restrict__ wfrag, const float *__restrict__ featp,
-                                               float *__restrict__ respp, unsigned char *sm_f, int *next_item, const ConvTile tile)
+                                               float *__restrict__ respp, unsigned char *sm_f, const ConvTile tile)
 {
     constexpr int kRec = MfmaRec<F16>::kBytes;
     constexpr int TW = kConvTW >> S, TH = kConvTH << S;
     constexpr int PW = TW + K - 1, PH = TH + K - 1;
     constexpr int NCELL = PW * PH;
     constexpr int MT = kMfmaFB / 32, NT = 8, NV = F16 ? 1 : 2;
+    static_assert(MT == 5 && NT == 8, "the static split over four waves below is written for 5 x 8 tile products");
     const int frame = p.frame0 + blockIdx.z;
     const int pass = blockIdx.y;                       // block of 160 filters
     const LevelDesc d = p.lv[tile.level];
@@ -104,7 +105,6 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 
             }
         }
     }
-    if (t == 0) *next_item = 0;
     __syncthreads();
 
     const int lane = t & 63;
@@ -116,129 +116,139 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams &p, const u32x4 
     constexpr size_t kStep = (size_t)MT * NV * 64;
     constexpr int NSTEP = K * K * 2;
     const size_t HW = (size_t)H * W;
+    using RT = typename std::conditional<F16, _Float16, float>::type;
 
-    // The 8 N-tiles are done in two halves of 4 (64 accumulator registers instead of 128): with ~110 registers per
-    // lane four waves fit a SIMD, so two or three 5-wave workgroups share a CU and one's matrix work covers the
-    // others' staging and stores.  The weights are streamed twice (from L2).
-    // N-tile groups per M-tile = work items per M-tile.  Measured (bf16, ms per step): 1 group (weights streamed once,
-    // 5 items over 4 waves) 8.1, 2 groups 7.8, 4 groups (weights streamed four times) 8.6
-    constexpr int NPART = 2;
-    constexpr int NH = NT / NPART;
-    // work item = (M-tile, half): 10 of them, handed out to the workgroup's FOUR waves through an LDS counter (five
-    // waves per workgroup would leave one SIMD with two: the second resident workgroup then rarely finds room)
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(next_item, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= MT * NPART) break;
-        const int m = item / NPART, half = item % NPART;
-        if (pass * kMfmaFB + m * 32 >= p.F) continue;              // no filters in this M-tile
-        // fragment stream of this M-tile: step s = tap * 2 + k-step; [s][m][v][lane]
-        const u32x4 *wsrc = wfrag + ((size_t)pass * (K * K * 2) * MT + m) * NV * 64 + lane;
-        const int f0 = pass * kMfmaFB + m * 32 + 4 * hh;
-        const int cellh = cell0 + half * NH * kNStep;
-        f32x16 acc[NH];
+    // One block of MB M-tiles (32 filters each) x NB N-tiles (32 pixels each) by one wave.  Per step (one tap, 16 channels):
+    // MB x NV weight fragments from L2 (fragment order, PF steps ahead, a ring of registers with static indices), NB x NV
+    // feature fragments from LDS, MB x NB x (F16 ? 1 : 3) MFMAs.  A feature fragment is single-buffered: the fragment of the
+    // NEXT step is requested right after the MFMAs that read the current one have been issued, and is needed a whole step later.
+    auto block = [&](auto mb_c, auto nb_c, auto pf_c, int m0, int n0) {
+        constexpr int MB = decltype(mb_c)::value, NB = decltype(nb_c)::value, PF = decltype(pf_c)::value;
+        static_assert(NSTEP % PF == 0, "the step loop runs in whole groups of PF");
+        const u32x4 *wsrc = wfrag + ((size_t)pass * (K * K * 2) * MT + m0) * NV * 64 + lane;
+        const int celln = cell0 + n0 * kNStep;
+        f32x16 acc[MB][NB];
 #pragma unroll
-        for (int n = 0; n < NH; ++n)
+        for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
-        // weight fragments PF steps ahead of their use (a ring of registers with static indices: the step loop runs in
-        // groups of PF): an L2 round trip is longer than the 4 (fp16) or 12 (bf16) MFMAs of one step
-        constexpr int PF = 5;
-        static_assert(NSTEP % (2 * PF) == 0, "the step loop runs in whole groups of 2 * PF");
-        u32x4 wq[PF][NV];
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][n][e] = 0.0f;
+        u32x4 wq[PF][MB][NV];
 #pragma unroll
         for (int j = 0; j < PF; ++j)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) wq[j][v] = wsrc[(size_t)j * kStep + v * 64];
-        // B fragments (features, LDS) of step s+1 are read while the MFMAs of step s run: two register sets
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) wq[j][mi][v] = wsrc[(size_t)j * kStep + (mi * NV + v) * 64];
         auto b_addr = [&](int sidx) {
             const int tp = sidx >> 1, kh = sidx & 1;
             const int ti = tp / K, tj = tp - ti * K;
-            return sm_f + (ti * PW + tj) * kRec + kh * 32 + cellh;
+            return sm_f + (ti * PW + tj) * kRec + kh * 32 + celln;
         };
-        u32x4 bq[2][NH][NV];
-        auto b_load = [&](int buf, int sidx) {
-            const unsigned char *bbase = b_addr(sidx);
+        u32x4 bq[NB][NV];
+        {
+            const unsigned char *bb = b_addr(0);
 #pragma unroll
-            for (int n = 0; n < NH; ++n)
+            for (int n = 0; n < NB; ++n)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) bq[buf][n][v] = *reinterpret_cast<const u32x4 *>(bbase + n * kNStep + v * 64);
-        };
-        b_load(0, 0);
-        static_assert(PF % 2 == 1 || NSTEP % 2 == 0, "buffer parity is static inside a group of PF steps");
+                for (int v = 0; v < NV; ++v) bq[n][v] = *reinterpret_cast<const u32x4 *>(bb + n * kNStep + v * 64);
+        }
 #pragma unroll 1
-        for (int s0 = 0; s0 < NSTEP; s0 += 2 * PF) {
+        for (int s0 = 0; s0 < NSTEP; s0 += PF) {
 #pragma unroll
-            for (int j = 0; j < 2 * PF; ++j) {
+            for (int j = 0; j < PF; ++j) {
                 const int sidx = s0 + j;
-                b_load((j + 1) & 1, min(sidx + 1, NSTEP - 1));
-                const int wj = j % PF;
-                if constexpr (F16) {
-                    const f16x8 af = __builtin_bit_cast(f16x8, wq[wj][0]);
+                const unsigned char *bnext = b_addr(min(sidx + 1, NSTEP - 1));
 #pragma unroll
-                    for (int n = 0; n < NH; ++n)
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, bq[j & 1][n][0]), acc[n], 0, 0, 0);
-                } else {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wq[wj][0]), al = __builtin_bit_cast(bf16x8, wq[wj][1]);
+                for (int n = 0; n < NB; ++n) {
+                    if constexpr (F16) {
+                        const f16x8 bf = __builtin_bit_cast(f16x8, bq[n][0]);
 #pragma unroll
-                    for (int n = 0; n < NH; ++n) {
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[j & 1][n][0]), bl = __builtin_bit_cast(bf16x8, bq[j & 1][n][1]);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                        for (int mi = 0; mi < MB; ++mi)
+                            acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq[j][mi][0]), bf, acc[mi][n], 0, 0, 0);
+                    } else {
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[n][0]), bl = __builtin_bit_cast(bf16x8, bq[n][1]);
+#pragma unroll
+                        for (int mi = 0; mi < MB; ++mi)
+                            acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[j][mi][0]), bh, acc[mi][n], 0, 0, 0);
+#pragma unroll
+                        for (int mi = 0; mi < MB; ++mi)
+                            acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[j][mi][0]), bl, acc[mi][n], 0, 0, 0);
+#pragma unroll
+                        for (int mi = 0; mi < MB; ++mi)
+                            acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wq[j][mi][1]), bh, acc[mi][n], 0, 0, 0);
                     }
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) bq[n][v] = *reinterpret_cast<const u32x4 *>(bnext + n * kNStep + v * 64);
                 }
                 const int snext = min(sidx + PF, NSTEP - 1);
 #pragma unroll
-                for (int v = 0; v < NV; ++v) wq[wj][v] = wsrc[(size_t)snext * kStep + v * 64];
+                for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) wq[j][mi][v] = wsrc[(size_t)snext * kStep + (mi * NV + v) * 64];
             }
         }
         // D layout (32x32): column = lane & 31 (pixel), row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) (filter).
         // The 16 plane pointers of a lane are formed by additions from one base (the products f * HW were two full-width
         // multiplies per store, and `f < F` a divergent region per store: more instructions than the fp16 mode's matrix work);
         // the filter test is uniform for every M-tile but the last (m_full).
-        const bool m_full = pass * kMfmaFB + m * 32 + 32 <= p.F;
-        using RT = typename std::conditional<F16, _Float16, float>::type;
-        RT *rbase = reinterpret_cast<RT *>(respp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)f0 * HW;
 #pragma unroll
-        for (int n = 0; n < NH; ++n) {
-            const int q = (half * NH + n) * 32 + r;
-            const int y = tile.y0 + q / TW, x = tile.x0 + q % TW;
-            if (x < W && y < H) {
-                RT *rp = rbase + (size_t)y * W + x;
-                if (m_full) {
+        for (int mi = 0; mi < MB; ++mi) {
+            const int f0 = pass * kMfmaFB + (m0 + mi) * 32 + 4 * hh;
+            const bool m_full = pass * kMfmaFB + (m0 + mi) * 32 + 32 <= p.F;
+            RT *rbase = reinterpret_cast<RT *>(respp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F + (size_t)f0 * HW;
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        RT *rg = rp + (size_t)(8 * g4) * HW;
+            for (int n = 0; n < NB; ++n) {
+                const int q = (n0 + n) * 32 + r;
+                const int y = tile.y0 + q / TW, x = tile.x0 + q % TW;
+                if (x < W && y < H) {
+                    RT *rp = rbase + (size_t)y * W + x;
+                    if (m_full) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { *rg = (RT)acc[n][4 * g4 + e]; rg += HW; }
-                    }
-                } else {
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            RT *rg = rp + (size_t)(8 * g4) * HW;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int fo = (e & 3) + 8 * (e >> 2);
-                        if (f0 + fo < p.F) rp[(size_t)fo * HW] = (RT)acc[n][e];
+                            for (int e = 0; e < 4; ++e) { *rg = (RT)acc[mi][n][4 * g4 + e]; rg += HW; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int fo = (e & 3) + 8 * (e >> 2);
+                            if (f0 + fo < p.F) rp[(size_t)fo * HW] = (RT)acc[mi][n][e];
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    // Static, balanced split of the 5 M-tiles x 8 N-tiles of the workgroup over its four waves, ten tile products each:
+    // wave (h, u) owns N-tiles 4h .. 4h+3; M-tiles 2u, 2u+1 against all four of them (a 2 x 4 block: every feature fragment
+    // read from LDS feeds six MFMAs, every weight fragment twelve), then M-tile 4 against N-tiles 4h+2u, 4h+2u+1 (1 x 2).
+    // Round 2 handed out ten 1 x 4 items through an LDS counter (4 + 4 + 2 items over four waves, twice the LDS reads):
+    // bf16 7.6 -> 6.75 ms, fp16 2.95 -> 2.83 ms per 64-frame step.  All ten products in ONE step loop (254 registers) was
+    // no faster in bf16 and slower in fp16 (3.4 ms); see profiles/r03_conv/README.md for where the rest of the time is.
+    auto mtile_used = [&](int m) { return pass * kMfmaFB + m * 32 < p.F; };
+    const int wv = t >> 6, h = wv >> 1, u = wv & 1;
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+    if (mtile_used(2 * u + 1)) block(I2{}, I4{}, I2{}, 2 * u, 4 * h);
+    else if (mtile_used(2 * u)) block(I1{}, I4{}, I5{}, 2 * u, 4 * h);
+    if (mtile_used(4)) block(I1{}, I2{}, I5{}, 4, 4 * h + 2 * u);
 }
 
 template <int K, bool F16>
 // two workgroups of four waves per CU (LDS: 62 KB each in bf16 mode): two waves per SIMD is what the kernel gets, so that is
 // what it asks for -- a request of three made the compiler squeeze to 168 registers it could not reach (220) for nothing
-__global__ __launch_bounds__(256, F16 ? 4 : 2) void k_conv_mfma(ConvParams p, const u32x4 *__restrict__ wfrag,
+__global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p, const u32x4 *__restrict__ wfrag,
                                                                       const float *__restrict__ featp, float *__restrict__ respp)
 {
     __shared__ __attribute__((aligned(16))) unsigned char sm_f[433 * MfmaRec<F16>::kBytes];
-    __shared__ int next_item;
     const int b = blockIdx.x;
     const ConvTile tile = p.shaped[b];
-    if (b < p.nshaped[0]) conv_mfma_tile<K, F16, 0>(p, wfrag, featp, respp, sm_f, &next_item, tile);
-    else if (b < p.nshaped[0] + p.nshaped[1]) conv_mfma_tile<K, F16, 1>(p, wfrag, featp, respp, sm_f, &next_item, tile);
-    else conv_mfma_tile<K, F16, 2>(p, wfrag, featp, respp, sm_f, &next_item, tile);
+    if (b < p.nshaped[0]) conv_mfma_tile<K, F16, 0>(p, wfrag, featp, respp, sm_f, tile);
+    else if (b < p.nshaped[0] + p.nshaped[1]) conv_mfma_tile<K, F16, 1>(p, wfrag, featp, respp, sm_f, tile);
+    else conv_mfma_tile<K, F16, 2>(p, wfrag, featp, respp, sm_f, tile);
 }
 
 int conv_mfma_occupancy(bool f16)
