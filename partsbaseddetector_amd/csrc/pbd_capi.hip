@@ -694,7 +694,7 @@ int upload_filters_t(pbd_handle *h, int nfilters, const void *const *filters, co
 {
     if (nfilters <= 0) return fail(h, PBD_ERR_INVALID, "no filters");
     for (int f = 0; f < nfilters; ++f)
-        if (ksize[f] < 1 || ksize[f] > 7) return fail(h, PBD_ERR_UNSUPPORTED, "filter %d: size %d not supported (1..7)", f, ksize[f]);
+        if (ksize[f] < 1 || ksize[f] > kConvMaxK) return fail(h, PBD_ERR_UNSUPPORTED, "filter %d: size %d not supported (1..%d)", f, ksize[f], kConvMaxK);
     // size classes in order of first appearance
     std::vector<int> sizes;
     for (int f = 0; f < nfilters; ++f)
@@ -1159,6 +1159,11 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
         // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
         const long long wgs = (long long)P.ntiles * nb;
         cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
+        {   // channels staged at a time: all 32 when the haloed tile fits the CU's LDS, else the largest power of two within 64 KB
+            const size_t plane = (size_t)(((kConvTH + C.K - 1) * (kConvTW + C.K - 1)) | 1) * h->rs;
+            cp.cblock = 32;
+            if (32 * plane > (size_t)160 * 1024) { cp.cblock = 16; while (cp.cblock > 1 && cp.cblock * plane > (size_t)64 * 1024) cp.cblock /= 2; }
+        }
         cp.wts3 = C.wts3.p;
         cp.unit_f0 = C.unit_f0.d; cp.unit_ql = C.unit_ql.d; cp.unit_woff = C.unit_woff.d; cp.nunits = C.nunits;
         cp.c31tab = C.c31tab.d; cp.c31stride = C.c31stride;

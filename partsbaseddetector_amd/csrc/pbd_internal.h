@@ -63,12 +63,16 @@ struct DtJob {
     double ax, bx, ay, by;    // Quadratic(-w0,-w1), Quadratic(-w2,-w3)  (src/DynamicProgram.cpp:125-127)
 };
 
+// mixtures per part the job tables and the register arrays of the combine / root kernels are sized for (the reference has no
+// limit, include/Parts.hpp:51-261; Person_26parts has 6, Face_68parts 1)
+constexpr int kMaxMix = 16;
+
 // one child part of a combine job
 struct ChildDesc {
     int job_begin;            // first DtJob (index within the group) of this child
     int nmix;                 // child mixtures K
     int slot;                 // back-pointer slot of (child, parent mixture 0) = ptr_slot[child]
-    int bias_off[8];          // biasid[child][mm], mm < K (add the parent mixture)
+    int bias_off[kMaxMix];          // biasid[child][mm], mm < K (add the parent mixture)
 };
 
 // combine job = one PARENT part: for every parent mixture m
@@ -78,12 +82,12 @@ struct CombineJob {
     int child_begin, child_end;   // range in the ChildDesc list, descending child index
     int npar;                     // parent mixtures L
     int acc_plane;                // global mixture index of (parent, mixture 0)
-    int filter[8];                // response plane of (parent, m)
+    int filter[kMaxMix];                // response plane of (parent, m)
 };
 
 struct RootJob {              // one per component
     int nmix;
-    int plane[8];             // response plane (filter id) or accumulated-score plane per root mixture
+    int plane[kMaxMix];             // response plane (filter id) or accumulated-score plane per root mixture
     int from_acc;             // bit mm set: plane[mm] is an accumulated-score plane
     float bias;
 };
@@ -96,25 +100,25 @@ struct SeqCombineJob {
     int job_begin;            // first DtJob of the part within the step
     int nmix;                 // the part's mixtures K
     int slot;                 // back-pointer slot of (part, parent mixture 0)
-    int bias_off[8];          // biasid[part][mm]
+    int bias_off[kMaxMix];          // biasid[part][mm]
     int npar;                 // parent mixtures L
-    int target[8];            // accumulated-score plane (component * F + filter id of (parent, pm))
-    int filter[8];            // filter id of (parent, pm): the plane the accumulator starts from
-    int init[8];              // 1: the accumulator has not been touched yet -> start from the raw response (:155)
+    int target[kMaxMix];            // accumulated-score plane (component * F + filter id of (parent, pm))
+    int filter[kMaxMix];            // filter id of (parent, pm): the plane the accumulator starts from
+    int init[kMaxMix];              // 1: the accumulator has not been touched yet -> start from the raw response (:155)
 };
 
 struct PartWalk {             // argmin tree walk, one per part of a component
     int parent;               // local parent index
     int slot;                 // ptr_slot
     int mix0;                 // global (part, mixture) index of the part's mixture 0
-    int ksize[8];             // filter size per mixture (xsize == ysize == rows, include/Parts.hpp:185-187)
+    int ksize[kMaxMix];             // filter size per mixture (xsize == ysize == rows, include/Parts.hpp:185-187)
 };
 
-constexpr int kMaxMix = 8;
 constexpr int kWalkMaxParts = 160;   // parts per component the back-tracking walk holds in LDS (Face_68parts: 68, Person_26parts: 26)
 // bytes of one spilled PAIR of envelope-stack entries {T sa, sb, za; unsigned vv;} (natural alignment of T)
 constexpr size_t kStkPairF32 = 16, kStkPairF64 = 32;
 constexpr int kConvTW = 32, kConvTH = 8, kConvQ = 8;
+constexpr int kConvMaxK = 31;        // largest filter side of the generic convolution kernel (the reference has no limit)
 #ifndef PBD_CONV3_NW
 #define PBD_CONV3_NW 8
 #endif
@@ -165,6 +169,7 @@ struct ConvParams {
     int nf, Fpad, ksize;          // this launch: filters of one size class, padded to kConvQ, their size
     const int *fmap;              // class-local filter index -> response plane (NULL: identity, the single-class case)
     int groups_per_block;         // filter groups (of kConvQ) handled by one workgroup
+    int cblock;                   // generic kernel: channels of the haloed tile staged in LDS at a time (32, or less for large filters)
     // k_conv3: the bank cut into units of 2 / 4 / 6 / 8 filters, weights per unit [32][25][QL]
     const void *wts3;
     const int *unit_f0, *unit_ql; // first filter (class-local index) and filters of a unit

@@ -390,18 +390,21 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
     const int t = threadIdx.x;
     const R *feat = static_cast<const R *>(p.feat) + ((size_t)frame * p.cell_per_frame + d.cell_off) * 32;
     const R *wts = static_cast<const R *>(p.wts);
-    {
-        const int c = t & 31;
-        const R border = (c == 31) ? (R)1 : (R)0;
-        for (int ci = t >> 5; ci < PH * PW; ci += 8) {
+    // CB channels of the haloed tile at a time: all 32 when they fit LDS (staged once for every filter group), fewer for
+    // large filters / T = double (then every group restages its channel blocks: a few loads per thread against CB * K * K * 8
+    // multiply-adds).  The per-filter order of the sums does not depend on CB.
+    const int CB = p.cblock;
+    auto stage = [&](int c0) {
+        for (int idx = t; idx < PH * PW * CB; idx += 256) {
+            const int ci = idx / CB, c = c0 + idx - ci * CB;
             const int cy = ci / PW, cx = ci - cy * PW;
             const int gy = tile.y0 + cy - a, gx = tile.x0 + cx - a;
-            R v = border;
+            R v = (c == 31) ? (R)1 : (R)0;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = feat[((size_t)gy * W + gx) * 32 + c];
-            smd[c * PLANE + ci] = v;
+            smd[(c - c0) * PLANE + ci] = v;
         }
-    }
-    __syncthreads();
+    };
+    if (CB == 32) { stage(0); __syncthreads(); }
     const int px = t & 31, py = t >> 5;
     const int x = tile.x0 + px, y = tile.y0 + py;
     const bool valid = (x < W) && (y < H);
@@ -415,7 +418,8 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
 #pragma unroll
         for (int q = 0; q < Q; ++q) r[q] = (R)0;
         for (int c = 0; c < 32; ++c) {
-            const R *sp = smd + c * PLANE + py * PW + px;
+            if (CB != 32 && c % CB == 0) { __syncthreads(); stage(c); __syncthreads(); }
+            const R *sp = smd + (c % CB) * PLANE + py * PW + px;
             const R *wp = wts + (size_t)c * (K * K) * p.Fpad + g * Q;
             R s[Q];
 #pragma unroll
@@ -455,7 +459,7 @@ template <typename R, bool FMA>
 static void launch_generic(const ConvParams &p, dim3 grid, hipStream_t s)
 {
     const int PW = kConvTW + p.ksize - 1, PH = kConvTH + p.ksize - 1;
-    const size_t lds = (size_t)32 * ((PH * PW) | 1) * sizeof(R);
+    const size_t lds = (size_t)p.cblock * ((PH * PW) | 1) * sizeof(R);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_generic<R, FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     PBD_LAUNCH((k_conv_generic<R, FMA>), grid, dim3(256), lds, s, p);
 }

@@ -510,15 +510,16 @@ void k_dp_combine(DpParams p)
     // space keeps them on the scalar unit (a plain global load after the first store would be a vector load
     // the compiler has to wait for at every use)
     const int __attribute__((address_space(4))) *childs = (const int __attribute__((address_space(4))) *)p.childs;
-    static_assert(sizeof(ChildDesc) == 11 * sizeof(int), "ChildDesc is read as 11 ints");
+    constexpr int kChildInts = 3 + kMaxMix;
+    static_assert(sizeof(ChildDesc) == kChildInts * sizeof(int), "ChildDesc is read as 3 + kMaxMix ints");
     const float __attribute__((address_space(4))) *biasw = (const float __attribute__((address_space(4))) *)p.biasw;
     for (int ch = cj.child_begin; ch < cj.child_end; ++ch) {
         ChildDesc cd;
         {
-            const int __attribute__((address_space(4))) *ci = childs + (size_t)ch * 11;
+            const int __attribute__((address_space(4))) *ci = childs + (size_t)ch * kChildInts;
             cd.job_begin = ci[0]; cd.nmix = ci[1]; cd.slot = ci[2];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cd.bias_off[k] = ci[3 + k];
+            for (int k = 0; k < MAXM; ++k) cd.bias_off[k] = ci[3 + k];
         }
         const size_t gbase = gbase0 + (size_t)cd.job_begin * HW;
         float bw[MAXM][MAXM]; // bias(mm)[pm]
@@ -597,7 +598,8 @@ void launch_dp_combine(const DpParams &p, int ncjobs, int nframes, bool f64, hip
     if (p.max_mix <= 2) PBD_COMBINE(2);
     else if (p.max_mix <= 4) PBD_COMBINE(4);
     else if (p.max_mix <= 6) PBD_COMBINE(6);
-    else PBD_COMBINE(8);
+    else if (p.max_mix <= 8) PBD_COMBINE(8);
+    else PBD_COMBINE(16);
 #undef PBD_COMBINE
 }
 

@@ -593,6 +593,33 @@ def test_model_with_filters_of_different_sizes(det_mod, oracle, dtype):
     det.hd.close()
 
 
+@pytest.mark.parametrize("dtype,ksizes,nmix", [(np.float32, [9, 12, 5], 3), (np.float64, [9, 8], 2), (np.float32, [5], 12), (np.float64, [3], 10)])
+def test_large_filters_and_many_mixtures(det_mod, oracle, dtype, ksizes, nmix):
+    """The reference sizes nothing at compile time (include/Parts.hpp:51-261, src/SpatialConvolutionEngine.cpp:141-158).  Filters
+    larger than 7 x 7 run on the generic kernel -- with the haloed tile staged a few channels at a time when 32 channels do
+    not fit LDS (T = double from 9 x 9 on) -- and parts with more than 8 mixtures on the 16-wide combine / root kernels:
+    responses of every filter size and all candidates bit for bit against the oracle."""
+    model = M.synthetic_model(seed=29 + nmix, pa=[0, 1, 1, 2], nmix=nmix, ksize=ksizes, interval=5, thresh=-1e9, name="large")
+    flat = model.flatten()
+    assert max(int(k) for k in flat.filter_ksize) == max(ksizes)
+    im = synth.synthetic_frame(43, 140, 120, 3)
+    want = oracle.detect(flat, im, dtype=dtype)
+    model.thresh = float(np.sort([w["score"] for w in want])[-50])
+    flat = model.flatten()
+    want = oracle.detect(flat, im, dtype=dtype)
+    det = det_mod.PartsBasedDetector(device=0, dtype=dtype)
+    det.distributeModel(model)
+    got = det.detect(im)
+    _compare_candidates(got, want)
+    feats, _ = oracle.features_pyramid(flat, im, dtype=dtype)
+    for l in (0, len(feats) - 1):
+        H, W = feats[l].shape[0], feats[l].shape[1] // 32
+        r = det.hd.get_stage(1, 0, l, H, W)
+        wr = oracle.responses(flat, feats[l])
+        assert r.dtype == wr.dtype and np.array_equal(r.view(np.uint8), wr.view(np.uint8))
+    det.hd.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_filter_shared_inside_a_component(det_mod, oracle, dtype):
     """A filter id referenced by more than one (part, mixture) of a component: the reference keys the accumulated
@@ -720,7 +747,7 @@ def test_failed_set_filters_keeps_the_old_bank(det_mod, oracle):
         conv = det_mod.SpatialConvolutionEngine(hd)
         before = conv.pdf([feat])[0]
         bad = [rng.standard_normal((3, 3 * 32)).astype(np.float32) for _ in range(4)] if mode == _lib.CONV_MFMA else \
-              [rng.standard_normal((9, 9 * 32)).astype(np.float32) for _ in range(4)]            # 9x9: outside 1..7 in every mode
+              [rng.standard_normal((33, 33 * 32)).astype(np.float32) for _ in range(4)]          # 33x33: outside 1..31 in every mode
         with pytest.raises(PbdError) as e:
             conv.setFilters(bad)
         assert e.value.code == -2
