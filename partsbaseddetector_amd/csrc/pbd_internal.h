@@ -204,6 +204,7 @@ struct DpParams {
     void *tmp, *dt;               // R [chunk][cell_per_frame*JG]
     long long quad_per_frame;
     int max_mix;                  // largest number of mixtures of any part of the model (<= kMaxMix)
+    int lane_shift;               // distance-transform passes: 64 >> lane_shift rows (columns) per wave (set per launch)
     // the transform's own pointers, row-major, KEPT for the whole batch ([frames][cell_per_frame*NJ], plane = DtJob::gm; uint8
     // when ptr8, else int16): IxRaw from the rows pass (stored TRANSPOSED, [x][y], as that pass writes it), IyRaw[y][x] from the columns pass.  The reference's Ix / Iy of a
     // (part, parent mixture) slot are Ix = IxRaw[k][y][x], Iy = IyRaw[k][y][Ix] with k = Ik (include/DistanceTransform.hpp:233-244,

@@ -257,7 +257,13 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     constexpr int EPW = 4 / (int)sizeof(PT);
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
     // the large levels are dispatched first and the tail of the launch is made of short ones
-    const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // lane_shift (0 .. 4): a group of 64 flat rows is spread over 1 .. 16 waves that use their first 64 .. 4 lanes only.
+    // A launch that does not fill the chip anyway (one frame, a few 1080p frames) then runs as more, narrower waves: the wave's
+    // pop loops iterate for the slowest of 16 lanes instead of 64, and the launch takes what its longest rows take (launch_dt_rows).
+    static_assert(kDtWaves == 1, "one wave per workgroup");
+    const int sh = p.lane_shift, lanep = threadIdx.x;
+    if (lanep >= (64 >> sh)) return;
+    const int wv = (int)blockIdx.z >> sh, lane = (((int)blockIdx.z & ((1 << sh) - 1)) << (6 - sh)) + lanep;
     if (wv * 64 >= p.nrows_flat) return;
     const int r = wv * 64 + lane;
     const bool active = r < p.nrows_flat;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     R *tmpT = static_cast<R *>(p.tmp) + jb + (size_t)y;
     PT *ixT = static_cast<PT *>(p.IxRaw) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + (size_t)y;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
-    DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
+    DtRing<R> ring = DtRing<R>::make(ring_mem, 0, lanep,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
                                          ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane, job.ax, job.bx);
     const int N = active ? W : 0;
@@ -330,11 +336,23 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     dt_stream<R, false, BZ, kDtCH, EPW>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
 }
 
-void launch_dt_rows(const DpParams &p, int nframes, bool f64, hipStream_t s)
+// Rows (columns) per wave of a pass: 64 when the launch fills the chip (1024 SIMDs), else 32 .. 4 -- see k_dt_rows.
+static int dt_lane_shift(long long waves64)
 {
-    if (p.JG == 0 || p.nrows_flat == 0) return;
-    const int nwv = (p.nrows_flat + 63) / 64;
-    dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
+    static const int forced = getenv("PBD_DT_LANESHIFT") ? atoi(getenv("PBD_DT_LANESHIFT")) : -1;
+    if (forced >= 0 && forced <= 4) return forced;
+    int sh = 0;
+    while (sh < 4 && (waves64 << (sh + 1)) <= 6144) ++sh;       // at most one round of waves (six per SIMD)
+    return sh;
+}
+
+void launch_dt_rows(const DpParams &p0, int nframes, bool f64, hipStream_t s)
+{
+    if (p0.JG == 0 || p0.nrows_flat == 0) return;
+    const int nwv = (p0.nrows_flat + 63) / 64;
+    DpParams p = p0;
+    p.lane_shift = dt_lane_shift((long long)p.JG * nframes * nwv);
+    dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_ROWS(PT, BZ)                                                                                              \
     do {                                                                                                              \
         if (f64) PBD_LAUNCH((k_dt_rows<double, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);          \
@@ -352,7 +370,9 @@ __global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(s
 void k_dt_cols(DpParams p)
 {
     constexpr int EPW = 4 / (int)sizeof(PT);
-    const int wv = blockIdx.z * kDtWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // longest columns first, as in the rows pass
+    const int sh = p.lane_shift, lanep = threadIdx.x;                                      // as in the rows pass
+    if (lanep >= (64 >> sh)) return;
+    const int wv = (int)blockIdx.z >> sh, lane = (((int)blockIdx.z & ((1 << sh) - 1)) << (6 - sh)) + lanep;   // longest columns first
     const int cidx = wv * 64 + lane;
     if (cidx >= p.ncols_flat) return;
     const int j = blockIdx.x, fl = blockIdx.y;
@@ -367,7 +387,7 @@ void k_dt_cols(DpParams p)
     R *dt = static_cast<R *>(p.dt) + jbase + x;
     PT *iyr = static_cast<PT *>(p.IyRaw) + ((size_t)(p.frame0 + fl) * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + x;
     __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
-    DtRing<R> ring = DtRing<R>::make(ring_mem, threadIdx.x >> 6, lane,
+    DtRing<R> ring = DtRing<R>::make(ring_mem, 0, lanep,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
                                          ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane, job.ay, job.by);
     auto load = [&](int q0, R *buf) {
@@ -399,11 +419,13 @@ void k_dt_cols(DpParams p)
     dt_stream<R, false, BZ, kDtCHC, EPW>(H, job.ay, job.by, job.osy, ring, load, store, noaux);
 }
 
-void launch_dt_cols(const DpParams &p, int nframes, bool f64, hipStream_t s)
+void launch_dt_cols(const DpParams &p0, int nframes, bool f64, hipStream_t s)
 {
-    if (p.JG == 0 || p.ncols_flat == 0) return;
-    const int nwv = (p.ncols_flat + 63) / 64;
-    dim3 grid(p.JG, nframes, (nwv + kDtWaves - 1) / kDtWaves);
+    if (p0.JG == 0 || p0.ncols_flat == 0) return;
+    const int nwv = (p0.ncols_flat + 63) / 64;
+    DpParams p = p0;
+    p.lane_shift = dt_lane_shift((long long)p.JG * nframes * nwv);
+    dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_COLS(PT, BZ)                                                                                   \
     do {                                                                                                   \
         if (f64) PBD_LAUNCH((k_dt_cols<double, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);      \

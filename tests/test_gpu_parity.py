@@ -843,3 +843,48 @@ def test_fused_path_responses_every_level(det_mod, oracle):
             checked += 1
         assert checked >= 10 and min(int(plan["feat_rows"][-1]), int(plan["feat_cols"][-1])) <= 5
         det.hd.close()
+
+
+def test_narrow_wave_distance_transform(det_mod, oracle):
+    """Launches of the distance-transform passes that do not fill the chip run as more, narrower waves (64 >> lane_shift rows
+    per wave, chosen per launch: pbd_kernels_dp.hip, dt_lane_shift).  The rows' arithmetic is untouched, so every setting must
+    give the oracle's candidates: each of 64 / 32 / 16 / 8 / 4 rows per wave is forced in a fresh interpreter
+    (PBD_DT_LANESHIFT is read once per process) on a frame with rows of up to 78 cells and int16-free uint8 planes, and once
+    on a frame wide enough for int16 planes."""
+    import hashlib, json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "from partsbaseddetector_amd import detector, synth, model as M\n"
+        "out = {}\n"
+        "for name, shape, sbin in (('u8', (150, 330), 4), ('i16', (60, 1100), 4)):\n"
+        "    model = M.synthetic_model(seed=31, pa=[0, 1, 1, 2, 2, 3], nmix=3, sbin=sbin, interval=4, thresh=-0.35, linear_def=(name == 'i16'), name='narrow')\n"
+        "    det = detector.PartsBasedDetector(device=0)\n"
+        "    det.distributeModel(model)\n"
+        "    cands = det.detect(synth.synthetic_frame(47, shape[0], shape[1], 3))\n"
+        "    h = hashlib.sha256()\n"
+        "    for c in cands:\n"
+        "        h.update(np.asarray([c.level, c.component, c.root[0], c.root[1]], np.int32).tobytes()); h.update(np.float32(c.score()).tobytes()); h.update(np.ascontiguousarray(c.parts, dtype=np.int32).tobytes())\n"
+        "    out[name] = [len(cands), h.hexdigest()]\n"
+        "    det.hd.close()\n"
+        "print(json.dumps(out))\n" % root)
+    results = {}
+    for shift in ("auto", "0", "1", "2", "3", "4"):
+        env = dict(os.environ)
+        env.pop("PBD_DT_LANESHIFT", None)
+        if shift != "auto":
+            env["PBD_DT_LANESHIFT"] = shift
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        results[shift] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert all(v == results["0"] for v in results.values()), results
+    assert results["0"]["u8"][0] > 10 and results["0"]["i16"][0] > 10
+    # and the 64-rows-per-wave result is the oracle's
+    for name, shape in (("u8", (150, 330)), ("i16", (60, 1100))):
+        model = M.synthetic_model(seed=31, pa=[0, 1, 1, 2, 2, 3], nmix=3, sbin=4, interval=4, thresh=-0.35, linear_def=(name == "i16"), name="narrow")
+        want = oracle.detect(model.flatten(), synth.synthetic_frame(47, shape[0], shape[1], 3))
+        h = hashlib.sha256()
+        for w in want:
+            h.update(np.asarray([w["level"], w["component"], w["root_x"], w["root_y"]], np.int32).tobytes()); h.update(np.float32(w["score"]).tobytes())
+            h.update(np.ascontiguousarray(w["parts"], dtype=np.int32).tobytes())
+        assert [len(want), h.hexdigest()] == results["0"][name], (name, len(want), results["0"][name])
