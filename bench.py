@@ -64,6 +64,11 @@ def parse():
                     help="skip the run of the other convolution mode / the agreement check")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="handles (HIP streams + workspaces) the batches are fed to round-robin: batches on different handles overlap "
+                         "at kernel granularity.  Pays for batches that do not fill the chip (one frame: +54 %%, 8 x 1080p: +8 %%); at the "
+                         "default 64 x 640x480 it is within 1 %% and the per-kernel durations `roofline` is priced on are then those of "
+                         "overlapped kernels, so the default stays 1")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 rehearsal of the multi-GPU step: initialise torch.distributed (world size 1) and issue the RCCL all_gather of the device-resident candidate payload every step")
     return ap.parse_args()
@@ -122,9 +127,17 @@ def main():
     flat = model.flatten()
     B, rows, cols, cn = args.batch, args.rows, args.cols, 3
     cap = max(1 << 16, int(B * rows * cols / (480 * 640) * 1024))      # candidate capacity: ~100 per VGA frame at the synthetic threshold, 10x head-room
-    det = PartsBasedDetector(device=local_rank, conv_mode={"exact": _lib.CONV_EXACT, "fma": _lib.CONV_FMA, "mfma": _lib.CONV_MFMA, "mfma_f16": _lib.CONV_MFMA_F16}[args.conv_mode],
-                             max_batch=B, max_candidates=cap)
-    det.distributeModel(model)
+    # K handles = K HIP streams + K workspaces fed round-robin (detector.DetectorPool): the kernels of one batch leave parts of
+    # the chip idle (tails of the distance-transform launches, launches smaller than the chip), and batches on different
+    # streams fill them.  Every batch is still computed by exactly one handle; `det` (lane 0) carries the per-kernel events.
+    NS = max(1, args.streams)
+    conv_mode = {"exact": _lib.CONV_EXACT, "fma": _lib.CONV_FMA, "mfma": _lib.CONV_MFMA, "mfma_f16": _lib.CONV_MFMA_F16}[args.conv_mode]
+    dets = []
+    for _ in range(NS):
+        d_ = PartsBasedDetector(device=local_rank, conv_mode=conv_mode, max_batch=B, max_candidates=cap)
+        d_.distributeModel(model)
+        dets.append(d_)
+    det = dets[0]
     stride = det.hd.stride
 
     # synthetic frames, seed = global frame index + 1; resident in HBM before the timed region
@@ -139,9 +152,13 @@ def main():
     cap_g = 16384
     dev = torch.device("cuda", local_rank)
     on_device = use_dist and args.backend == "nccl"
-    gatherer = (pdist.CandidateGatherer(stride, cap_g, dev if on_device else "cpu", force_collective=args.force_collective, cap_full=cap)
-                if use_dist else None)
-    dgather = pdist.DeviceBatchGather(det, gatherer) if on_device else None
+    # one gatherer per lane (its own send / receive buffers and pending slot): every rank walks the lanes in the same order, so
+    # the collectives are issued in the same order everywhere
+    gatherers = [pdist.CandidateGatherer(stride, cap_g, dev if on_device else "cpu", force_collective=args.force_collective, cap_full=cap)
+                 for _ in range(NS)] if use_dist else None
+    gatherer = gatherers[0] if use_dist else None
+    dgathers = [pdist.DeviceBatchGather(dets[i], gatherers[i]) for i in range(NS)] if on_device else None
+    dgather = dgathers[0] if on_device else None
     gathered = [0]
     ncand_last = [0]
 
@@ -149,16 +166,18 @@ def main():
         if rec is not None:
             gathered[0] = len(rec)
 
-    def run(steps):
+    def run(steps, K=NS):
         """`steps` passes of the hot path over the resident batch, pipelined one batch deep: the host never waits for batch
         k before batch k+1 is enqueued, so the candidates' read-back (N = 1) or gather (N > 1) of batch k runs under the
         kernels of batch k+1.  Returns when every batch's candidate list is in host memory (rank 0: the gathered list)."""
         if dgather is not None:
             # N > 1 (RCCL): the candidate list never touches the host before the collective -- the walk kernel writes the
-            # [found | records] payload (global frame ids), all_gather_into_tensor reads a prefix of that tensor
-            for _ in range(steps):
-                note(dgather.submit(d_frames.data_ptr(), B, rows, cols, cn, frame_offset=rank * B, root_only=True))
-            note(dgather.collect(root_only=True))
+            # [found | records] payload (global frame ids), all_gather_into_tensor reads a prefix of that tensor.  Lane s % K:
+            # its submit() finishes the gather of the batch that lane took K steps ago and issues this batch's collective.
+            for s_ in range(steps):
+                note(dgathers[s_ % K].submit(d_frames.data_ptr(), B, rows, cols, cn, frame_offset=rank * B, root_only=True))
+            for i in range(min(K, steps)):                   # drain in submission order
+                note(dgathers[(steps - min(K, steps) + i) % K].collect(root_only=True))
         elif gatherer is not None:
             # gloo rehearsal: host records through the pinned staging buffer
             for _ in range(steps):
@@ -169,21 +188,32 @@ def main():
                 ncand_last[0] = n
             note(gatherer.finish(root_only=True))
         else:
-            det.submit_batch_device(d_frames.data_ptr(), B, rows, cols, cn)
-            for k in range(steps):
-                if k + 1 < steps:
-                    det.submit_batch_device(d_frames.data_ptr(), B, rows, cols, cn)
-                _, ncand_last[0] = det.wait_batch(raw=True)
+            # N = 1: batch s goes to lane s % K; a lane's previous batch is collected just before the lane is reused, so up to K
+            # batches are in flight (K = 1: one batch enqueued ahead of the one being collected, as in rounds 1-3)
+            if K == 1:
+                det.submit_batch_device(d_frames.data_ptr(), B, rows, cols, cn)
+                for k in range(steps):
+                    if k + 1 < steps:
+                        det.submit_batch_device(d_frames.data_ptr(), B, rows, cols, cn)
+                    _, ncand_last[0] = det.wait_batch(raw=True)
+            else:
+                for s_ in range(steps):
+                    if s_ >= K:
+                        _, ncand_last[0] = dets[s_ % K].wait_batch(raw=True)
+                    dets[s_ % K].submit_batch_device(d_frames.data_ptr(), B, rows, cols, cn)
+                for i in range(min(K, steps)):
+                    _, ncand_last[0] = dets[(steps - min(K, steps) + i) % K].wait_batch(raw=True)
 
     def sync():
-        det.hd.check(det.hd.lib.pbd_synchronize(det.hd.h))
+        for d_ in dets:
+            d_.hd.check(d_.hd.lib.pbd_synchronize(d_.hd.h))
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     if args.warmup > 0:
-        run(args.warmup)
+        run(max(args.warmup, NS))      # every lane once: plans, workspaces and pinned buffers are created on a handle's first batch
     # Inside the timed region only the dominant kernel (the convolution: one launch per step) carries HIP events -- that is
     # where `roofline` comes from.  Timing EVERY launch separates the ~45 dispatches of a step by about 9 us each
     # (profiles/r03_trace_gaps.txt: 393 us of idle GPU time per step with per-kernel events, 18 us without), so the full
@@ -203,7 +233,7 @@ def main():
         det.hd.profile(1)
         sync()
         t1 = time.perf_counter()
-        run(profiled_steps)
+        run(profiled_steps, 1)          # lane 0 alone: every launch timed, kernels not overlapped with another batch's
         sync()
         dt_prof = time.perf_counter() - t1
     if dgather is not None:
@@ -369,7 +399,7 @@ def main():
             odd = [r for k, r in list(ka.items()) + list(kb.items()) if k not in common]
             # a root present in only one mode must sit within the score tolerance of the threshold
             margin = max((abs(float(r[5:6].view(np.float32)[0]) - flat.thresh) for r in odd), default=0.0)
-            other_mode = {"conv_mode": oname, "value": round(B / edt, 3), "unit": "detections/s", "ms_per_step": round(edt * 1e3, 3),
+            other_mode = {"conv_mode": oname, "value": round(B / edt, 3), "unit": "detections/s", "ms_per_step": round(edt * 1e3, 3), "streams": 1,
                           "note": ("matrix-core convolution (bf16 hi/lo operand split, fp32 accumulation): responses within 1e-4, "
                                    "index outputs can differ on near ties (see agreement)") if oname == "mfma" else
                                   "bit-identical responses (reference summation order)"}
@@ -427,9 +457,12 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), RCCL all_gather of candidates",
                        "world_size": dist.get_world_size() if use_dist else 1,
                        "backend": dist.get_backend() if use_dist else None,
-                       "pipeline": "one batch deep: batch k+1 is enqueued before the candidate list of batch k is collected",
+                       "streams": NS,
+                       "pipeline": (f"{NS} handles (HIP streams + workspaces) fed round-robin, up to {NS} batches in flight: a handle's candidate list is "
+                                    "collected just before the handle is given its next batch" if NS > 1 else
+                                    "one batch deep: batch k+1 is enqueued before the candidate list of batch k is collected"),
                        "rank_ms_per_step": [round(v, 3) for v in rank_ms],
-                       "gather": ({"collectives_per_step": gatherer.collectives / max(args.steps + args.warmup, 1),
+                       "gather": ({"collectives_per_step": sum(g_.collectives for g_ in gatherers) / max(args.steps + (max(args.warmup, NS) if args.warmup > 0 else 0) + profiled_steps, 1),
                                    "capacity_records": gatherer.cap, "grown": gatherer.grown,
                                    "payload": "device-resident: written by the walk kernel, handed to all_gather_into_tensor as it is" if on_device else "host records (gloo rehearsal)",
                                    "overlap": "the collective of batch k runs under the kernels of batch k+1 (begin / finish one step apart)"} if gatherer else None)},
@@ -445,7 +478,8 @@ def main():
             "host_input": host_input,
         }
         print(json.dumps(out), flush=True)
-    det.hd.close()
+    for d_ in dets:
+        d_.hd.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -538,6 +538,51 @@ public:
     }
 };
 
+// A stream of single frames over K handles (K HIP streams + workspaces) of one GPU, fed round-robin -- new surface: the
+// reference's callers run detect(im) one frame at a time (cells/detect.cpp:213, ros/Node.cpp:144), and one frame's kernels do
+// not fill an MI355X; frames on different handles overlap at kernel granularity (one 640x480 frame: 338 -> 443 frames/s with
+// four handles).  Results come back in submission order and are those of detect() on one handle.
+//     FrameStream<float> fs(model, 4);
+//     for (;;) { while (fs.full()) { fs.next(cands); use(cands); }   fs.submit(frame); }
+//     while (fs.pending()) { fs.next(cands); use(cands); }
+// Frames are 8-bit (pbd_detect_batch_submit); a submitted frame's pixels are copied before submit() returns.
+template <typename T>
+class FrameStream {
+    std::vector<pbd_handle *> h_;
+    size_t submitted_, collected_;
+    int capacity_;
+    FrameStream(const FrameStream &);
+    FrameStream &operator=(const FrameStream &);
+public:
+    FrameStream(Model &model, int nhandles = 4, int device = 0, int capacity = 1 << 16) : submitted_(0), collected_(0), capacity_(capacity)
+    {
+        if (nhandles < 1) throw Error(PBD_ERR_INVALID, "FrameStream needs at least one handle");
+        for (int i = 0; i < nhandles; ++i) h_.push_back(pbdbind::create<HostTraits<T> >(model, device, PBD_CONV_EXACT, 1, capacity));
+    }
+    ~FrameStream() { for (size_t i = 0; i < h_.size(); ++i) pbd_destroy(h_[i]); }
+    size_t pending() const { return submitted_ - collected_; }
+    bool full() const { return pending() >= h_.size(); }        // the handle the next frame would go to still holds a result
+    void submit(const Image &im)
+    {
+        if (full()) throw Error(PBD_ERR_STATE, "FrameStream::submit(): every handle holds an uncollected frame; call next() first");
+        if (im.depth != 0) throw Error(PBD_ERR_UNSUPPORTED, "FrameStream takes 8-bit frames");
+        pbd_handle *h = h_[submitted_ % h_.size()];
+        const void *img = im.data;
+        pbdbind::check<HostTraits<T> >(h, pbd_detect_batch_submit(h, 1, &img, im.rows, im.cols, im.channels, im.step));
+        ++submitted_;
+    }
+    void next(std::vector<Candidate> &candidates)
+    {   // the oldest submitted frame's candidates
+        if (!pending()) throw Error(PBD_ERR_STATE, "FrameStream::next(): nothing submitted");
+        pbd_handle *h = h_[collected_ % h_.size()];
+        std::vector<int32_t> buf((size_t)capacity_ * pbd_candidate_stride(h) + 1);
+        int n = 0;
+        pbdbind::check<HostTraits<T> >(h, pbd_detect_batch_wait(h, &buf[0], capacity_, &n));
+        ++collected_;
+        pbdbind::unpack_candidates<HostTraits<T> >(h, buf, n, candidates);
+    }
+};
+
 // binary PGM (P5) / PPM (P6, stored RGB -> returned BGR as cv::imread does)
 inline bool readPNM(const std::string &path, std::vector<uint8_t> &pix, Image &im)
 {

@@ -12,7 +12,7 @@ def __getattr__(name):
     # the detector classes need the HIP library; import them lazily so that model/synth utilities
     # stay importable, and fail loudly (ImportError) when the library is absent
     if name in ("PartsBasedDetector", "HOGFeatures", "SpatialConvolutionEngine", "DynamicProgram", "Candidate",
-                "Handle", "PbdError"):
+                "Handle", "PbdError", "DetectorPool"):
         from . import detector
         return getattr(detector, name)
     raise AttributeError(name)

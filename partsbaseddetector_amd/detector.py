@@ -390,3 +390,69 @@ class PartsBasedDetector:
         if raw:
             return self._buf, n.value
         return self.hd.unpack_candidates(self._buf, n.value)
+
+
+class DetectorPool:
+    """K detectors of one model on one GPU -- K handles, i.e. K HIP streams and K workspaces -- fed round-robin.
+
+    A handle runs its kernels in order on its own stream; the kernels of one batch do not fill the chip all the time (the
+    distance-transform launches of a tree-depth group end in tails of short rows, a single frame's launches are smaller than
+    the chip).  Batches submitted to DIFFERENT handles overlap at kernel granularity: measured on MI355X, 3 handles give
+    +5 % at 64 frames of 640x480 per batch, +8 % at 8 frames of 1920x1080 and +54 % for a stream of single frames
+    (profiles/README.md).  Results come back in submission order; every batch is computed by exactly one handle, so they are
+    those of a single PartsBasedDetector.
+
+        pool = DetectorPool(model, n=3, max_batch=64)
+        for batch in stream:                       # frames resident on the device
+            pool.submit_batch_device(ptr, nframes, rows, cols, cn)
+            while pool.ready_before_next_submit: handle(pool.wait_batch())
+        while pool.pending: handle(pool.wait_batch())
+    """
+
+    def __init__(self, model: Model, n: int = 3, **kw):
+        if n < 1:
+            raise ValueError("DetectorPool needs at least one detector")
+        self.dets: List[PartsBasedDetector] = []
+        for _ in range(n):
+            d = PartsBasedDetector(**kw)
+            d.distributeModel(model)
+            self.dets.append(d)
+        self._submitted = 0         # batches submitted so far
+        self._collected = 0         # batches handed back so far
+
+    @property
+    def pending(self) -> int:
+        return self._submitted - self._collected
+
+    @property
+    def ready_before_next_submit(self) -> bool:
+        """True when the lane the next submit would use still holds an uncollected batch (collect one first)"""
+        return self.pending >= len(self.dets)
+
+    def _lane(self, i: int) -> "PartsBasedDetector":
+        return self.dets[i % len(self.dets)]
+
+    def submit_batch_device(self, d_frames_ptr: int, nframes: int, rows: int, cols: int, cn: int) -> None:
+        if self.ready_before_next_submit:
+            raise PbdError(-5, "DetectorPool: every lane holds an uncollected batch; call wait_batch() first")
+        self._lane(self._submitted).submit_batch_device(d_frames_ptr, nframes, rows, cols, cn)
+        self._submitted += 1
+
+    def submit_batch(self, frames: Sequence[np.ndarray]) -> None:
+        if self.ready_before_next_submit:
+            raise PbdError(-5, "DetectorPool: every lane holds an uncollected batch; call wait_batch() first")
+        self._lane(self._submitted).submit_batch(frames)
+        self._submitted += 1
+
+    def wait_batch(self, capacity: Optional[int] = None, raw: bool = False):
+        """the oldest uncollected batch's candidates (as PartsBasedDetector.wait_batch)"""
+        if not self.pending:
+            raise PbdError(-5, "DetectorPool.wait_batch(): nothing submitted")
+        out = self._lane(self._collected).wait_batch(capacity, raw)
+        self._collected += 1
+        return out
+
+    def close(self) -> None:
+        for d in self.dets:
+            if d.hd is not None:
+                d.hd.close()

@@ -365,3 +365,65 @@ def test_a_failed_rank_does_not_block_the_others():
     msgs = {r: m for r, m in got if isinstance(m, str)}
     assert set(msgs) == {0, 1} and all("rank(s) [1]" in m for m in msgs.values())
     assert sorted(m for r, m in got if not isinstance(m, str)) == [(4, 12), (4, 12)]
+
+
+def _lanes_worker(rank, world, port, q):
+    """bench.py's multi-stream loop over RCCL, rehearsed with CPU tensors: K lanes, each with its own CandidateGatherer; step s
+    goes to lane s % K, whose submit finishes the lane's previous gather (step s - K) and issues step s's collective"""
+    import torch.distributed as dist
+    from partsbaseddetector_amd import dist as pd
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        stride, K, steps = 12, 3, 8
+        lanes = [pd.CandidateGatherer(stride, cap=8, device="cpu", cap_full=64) for _ in range(K)]
+
+        def emit(g, step):
+            n = 1 + (step * 5 + rank * 3) % 11             # step 4 on rank 1 overflows the initial capacity of 8
+            p = g.payload.numpy()
+            p[0] = n
+            rec = p[1:1 + n * stride].reshape(n, stride)
+            rec[:] = 1000 * step + 100 * rank
+            rec[:, 0] = np.arange(n) + 50 * rank
+            return n
+
+        out, sent = [], []
+        for s in range(steps):
+            g = lanes[s % K]
+            sent.append(emit(g, s))
+            if g.pending:
+                out.append(g.finish(root_only=True))        # the records of step s - K
+            g.begin_device(None)
+        m = min(K, steps)
+        for i in range(m):                                   # drain in submission order
+            out.append(lanes[(steps - m + i) % K].finish(root_only=True))
+        q.put((rank, out, sent, sum(g.collectives for g in lanes), sum(g.grown for g in lanes)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_several_gatherers_in_flight_round_robin():
+    """K lanes with a gatherer each (bench.py --streams K at N > 1): up to K collectives are in flight, every rank issues them
+    in the same order, the records come back per step in submission order, and an overflow on one lane grows that lane only."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lanes_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, sent, ncoll, grown = q.get(timeout=180)
+        res[rank] = (out, sent, ncoll, grown)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    stride, steps = 12, 8
+    assert all(o is None for o in res[1][0]) and len(res[0][0]) == steps
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] >= 1          # the same collectives (incl. repeats) on both ranks
+    for s in range(steps):
+        rec = res[0][0][s]
+        n0, n1 = res[0][1][s], res[1][1][s]
+        assert rec.shape == (n0 + n1, stride)
+        assert np.array_equal(rec[:, 0], np.concatenate([np.arange(n0), np.arange(n1) + 50]))
+        assert np.array_equal(rec[:, 2], np.concatenate([np.full(n0, 1000 * s), np.full(n1, 1000 * s + 100)]))

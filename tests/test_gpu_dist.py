@@ -205,3 +205,44 @@ def test_rccl_world1_device_gather(tmp_path):
     assert res["grown"] == 1 and res["cap_after"] >= max(res["counts"]), res      # cap 4 -> grown once to fit every batch
     assert res["collectives"] == 4, res                                            # 3 batches + one repeat (found while batch 1 was already enqueued)
     assert res["host_ok"] and res["level_ok"] and res["restored"], res
+
+
+@pytest.mark.gpu
+def test_detector_pool_round_robin(oracle):
+    """detector.DetectorPool: K handles (streams + workspaces) fed round-robin.  Batches of different content and size go
+    through a pool of three; the results come back in submission order and equal the single-handle results of the same batches
+    record for record (and the oracle's for one frame)."""
+    import torch
+    from partsbaseddetector_amd import detector
+    model = M.synthetic_tiny_model()
+    flat = model.flatten()
+    batches = [np.stack([synth.synthetic_frame(10 * b + i + 1, 120, 160, 3) for i in range(n)]) for b, n in enumerate([3, 1, 4, 2, 4, 3, 1])]
+    dev = [torch.from_numpy(b).cuda() for b in batches]
+    single = detector.PartsBasedDetector(device=0, max_batch=4)
+    single.distributeModel(model)
+    want = []
+    for d in dev:
+        buf, n = single.detect_batch_device(d.data_ptr(), d.shape[0], 120, 160, 3, raw=True)
+        want.append(np.array(buf[: n * single.hd.stride]))
+    pool = detector.DetectorPool(model, n=3, device=0, max_batch=4)
+    got = []
+    for d in dev:
+        while pool.ready_before_next_submit:
+            buf, n = pool.wait_batch(raw=True)
+            got.append(np.array(buf[: n * single.hd.stride]))
+        pool.submit_batch_device(d.data_ptr(), d.shape[0], 120, 160, 3)
+    with pytest.raises(detector.PbdError):
+        for d in dev:                                 # more submits than lanes without collecting: refused, nothing lost
+            pool.submit_batch_device(d.data_ptr(), d.shape[0], 120, 160, 3)
+    while pool.pending:
+        buf, n = pool.wait_batch(raw=True)
+        got.append(np.array(buf[: n * single.hd.stride]))
+    assert len(got) >= len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert sum(len(w) for w in want) > 0
+    c0 = [c for c in single.hd.unpack_candidates(want[1], len(want[1]) // single.hd.stride)]
+    ref = oracle.detect(flat, batches[1][0])
+    assert len(c0) == len(ref)
+    pool.close()
+    single.hd.close()

@@ -36,9 +36,9 @@ def _write_inputs(tmp_path, model, im):
 
 def _parse(out):
     lines = out.strip().splitlines()
-    n = int(lines[0].split(":")[1])
+    n = int([ln for ln in lines if ln.startswith("Number of candidates")][0].split(":")[1])
     cands = []
-    for ln in lines[1:]:
+    for ln in lines:
         if not ln.startswith("cand "):
             continue
         t = ln.split()
@@ -120,13 +120,18 @@ def test_cpp_reader_rejects_malformed_xml(demo, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags,dtype", [([], np.float32), (["--staged"], np.float32), (["--double"], np.float64),
-                                         (["--double", "--staged"], np.float64)])
+                                         (["--double", "--staged"], np.float64),
+                                         (["--stream", "3", "10"], np.float32), (["--double", "--stream", "2", "5"], np.float64)])
 def test_demo_matches_oracle(demo, oracle, tmp_path, flags, dtype):
+    """--stream K N: the frame N times through pbdhost::FrameStream (K handles fed round-robin); the demo itself checks that all
+    N results are identical and prints the first, which must be the oracle's like a plain detect()."""
     model = M.synthetic_tiny_model(thresh=0.7)
     im = synth.synthetic_frame(5, 96, 128, 3)
     mpath, ipath = _write_inputs(tmp_path, model, im)
     r = subprocess.run([demo, mpath, ipath] + flags, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    if "--stream" in flags:
+        assert "results identical" in r.stdout
     n, got = _parse(r.stdout)
     want = oracle.detect(model.flatten(), im, dtype=dtype)
     assert n == len(want) == len(got)

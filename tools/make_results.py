@@ -49,6 +49,13 @@ def main():
     b1 = load("r03_bench_b1.json")
     if b1:
         rows.append(f"| one 640x480 frame per step (`--batch 1`) | {b1['value']:.0f} | {b1['ms_per_step']:.2f} |")
+    for name, label in (("r03_bench_b1s4.json", "one 640x480 frame per step over 4 handles (`--batch 1 --streams 4`, `detector.DetectorPool`)"),
+                        ("r03_bench_hd1.json", "one 1920x1080 frame per step"),
+                        ("r03_bench_hd1s3.json", "one 1920x1080 frame per step over 3 handles (`--streams 3`)"),
+                        ("r03_bench_hd8s3.json", "8 x 1920x1080 per step over 3 handles (`--streams 3`)")):
+        h = load(name)
+        if h:
+            rows.append(f"| {label} | {h['value']:.1f} | {h['ms_per_step']:.2f} |")
     o3 = cpu.get("O3") or {}
     rows.append(f"| CPU restatement, {cpu['cores']} OpenMP threads of the GPU box's host (`cpu_baseline`, kind \"port\"): -O2 / -O3 / one thread | {cpu['value']:.2f} / {o3.get('value', float('nan')):.2f} / {cpu['single_thread']['value']:.2f} | - |")
     rows.append("")
