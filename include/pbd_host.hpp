@@ -579,6 +579,7 @@ public:
         int n = 0;
         pbdbind::check<HostTraits<T> >(h, pbd_detect_batch_wait(h, &buf[0], capacity_, &n));
         ++collected_;
+        candidates.clear();
         pbdbind::unpack_candidates<HostTraits<T> >(h, buf, n, candidates);
     }
 };
