@@ -318,10 +318,10 @@ def main():
                 entry.update({"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                               "frac": round(ach / PEAK_HBM_GBPS, 4)})
                 if k in ("k_dt_rows", "k_dt_cols"):
-                    entry["note"] = ("priced against HBM as SURVEY 8(d) prescribes; with the per-lane spill stack the two passes move 2.6-2.8x their plane "
-                                     "I/O -- about 4 TB/s of fabric traffic while they run.  64 independent rows run in lock step (a lane needs 1.7 envelope "
-                                     "intersections per element, the wave executes 4.6); removing every fp64 division from the common path (round 3, bit-exact) "
-                                     "did not move them: profiles/r03_dt/README.md")
+                    entry["note"] = ("priced against HBM as SURVEY 8(d) prescribes, but the passes are bound by VALU issue (70-82 % busy): 200 instructions per element "
+                                     "and wave where the divergence-free skeleton needs 90 -- 64 independent rows in lock step run 2.45 pop iterations per element "
+                                     "where a lane needs 0.71.  Plane I/O plus the MAXIMUM possible spill traffic costs 3.5-4 ms per pass (uniform-control-flow "
+                                     "probes and counters: profiles/r03_dt/README.md section 6); launches that do not fill the chip run as narrower waves (section 7)")
             entry["wasted_traffic"] = round(entry["traffic"] / entry["algorithmic_bytes_per_launch"], 3) if entry["traffic"] else None
             roof_all.append(entry)
         if roof_all:

@@ -57,6 +57,47 @@ def test_resize_identity_and_bilinear(oracle):
     assert np.abs(out.astype(np.float64) - ref).max() <= 1.01
 
 
+def _resize_u8_numpy(im, dh, dw):
+    """SURVEY Appendix E's 8-bit INTER_LINEAR algorithm written again, vectorised and from the text alone (fixed point, 11
+    coefficient bits, horizontal pass in int, vertical pass ((b * (r >> 4)) >> 16 twice) + 2 >> 2) -- an independent statement
+    of the same published algorithm, not a second opinion on OpenCV itself (which nothing here can provide)."""
+    sh, sw = im.shape[:2]
+
+    def coef(dn, sn):
+        scale = 1.0 / (float(dn) / float(sn))
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = (f - s0.astype(np.float32)).astype(np.float32)
+        lo, hi = s0 < 0, s0 >= sn - 1
+        f = np.where(lo | hi, np.float32(0), f)
+        s0 = np.where(lo, 0, np.where(hi, sn - 1, s0))
+        a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)      # cvRound: half to even, as np.rint
+        a1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s0, np.minimum(s0 + 1, sn - 1), a0, a1
+
+    if (dh, dw) == (sh, sw):
+        return im.copy()
+    sx0, sx1, a0, a1 = coef(dw, sw)
+    sy0, sy1, b0, b1 = coef(dh, sh)
+    S = im.astype(np.int64)
+    R = S[:, sx0] * a0[None, :, None] + S[:, sx1] * a1[None, :, None]              # every source row, horizontally
+    r0, r1 = R[sy0], R[sy1]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape,dst", [((61, 83), (44, 59)), ((61, 83), (58, 80)), ((97, 131), (49, 66)), ((240, 320), (224, 299)),
+                                       ((50, 61), (37, 45))])
+@pytest.mark.parametrize("cn", [3, 1])
+def test_resize_u8_against_an_independent_integer_formulation(oracle, shape, dst, cn):
+    im = synth.synthetic_frame(9, shape[0], shape[1], cn)
+    if im.ndim == 2:
+        im = im[:, :, None]
+    got = oracle.resize_linear_u8(im if cn == 3 else im[:, :, 0], dst[0], dst[1])
+    want = _resize_u8_numpy(im, dst[0], dst[1])
+    assert np.array_equal(np.asarray(got).reshape(want.shape), want)
+
+
 def test_pyrdown_integer_formulation(oracle):
     for shape, cn in [((37, 52), 3), ((40, 41), 1), ((5, 4), 3)]:
         im = synth.synthetic_frame(9, shape[0], shape[1], cn, kind="noise")
