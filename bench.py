@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--streams", type=int, default=1,
                     help="handles (HIP streams + workspaces) the batches are fed to round-robin: batches on different handles overlap "
-                         "at kernel granularity.  Pays for batches that do not fill the chip (one frame: +54 %%, 8 x 1080p: +8 %%); at the "
+                         "at kernel granularity.  Pays for batches that do not fill the chip (one 640x480 frame: +30 %%, one 1080p frame: +21 %%); at the "
                          "default 64 x 640x480 it is within 1 %% and the per-kernel durations `roofline` is priced on are then those of "
                          "overlapped kernels, so the default stays 1")
     ap.add_argument("--force-collective", action="store_true",
