@@ -395,12 +395,12 @@ class PartsBasedDetector:
 class DetectorPool:
     """K detectors of one model on one GPU -- K handles, i.e. K HIP streams and K workspaces -- fed round-robin.
 
-    A handle runs its kernels in order on its own stream; the kernels of one batch do not fill the chip all the time (the
-    distance-transform launches of a tree-depth group end in tails of short rows, a single frame's launches are smaller than
-    the chip).  Batches submitted to DIFFERENT handles overlap at kernel granularity: measured on MI355X, 3 handles give
-    one 640x480 frame per step 337 -> 439 detections/s with four handles, one 1920x1080 frame 82 -> 100 with three; batches
-    that fill the chip (64 x 640x480, 8 x 1920x1080) gain nothing (profiles/r03_bench_*s*.json, profiles/r03_streams_*.txt).  Results come back in submission order; every batch is computed by exactly one handle, so they are
-    those of a single PartsBasedDetector.
+    A handle runs its kernels in order on its own stream; the kernels of a small batch do not fill the chip (a single frame's
+    launches are smaller than the chip).  Batches submitted to DIFFERENT handles overlap at kernel granularity.  Measured on
+    MI355X: one 640x480 frame per step 337 -> 439 detections/s with four handles, one 1920x1080 frame 82 -> 100 with three;
+    batches that fill the chip (64 x 640x480, 8 x 1920x1080) gain nothing (profiles/r03_bench_*s*.json,
+    profiles/r03_streams_*.txt).  Results come back in submission order; every batch is computed by exactly one handle, so
+    they are those of a single PartsBasedDetector.
 
         pool = DetectorPool(model, n=3, max_batch=64)
         for batch in stream:                       # frames resident on the device
