@@ -103,23 +103,31 @@ constexpr int kDtT = PBD_DT_RING;    // ring entries per lane (power of two)
 
 // LDS layout of a wave's ring: [slot][z: 64 x R | s: 64 x R | v: 64 x int]; one address per lane, the rest
 // are immediate offsets.
-template <typename R>
+// NARROW (launches that do not fill the chip, see k_dt_rows: the wave uses its first L = 64 >> lane_shift lanes only): the same
+// 6 KB hold kDtT << lane_shift entries per lane, laid out [slot][z: L x R | s: L x R | v: L x int] -- with 16 lanes the ring is
+// 32 deep, with 4 lanes 128: rows of a VGA pyramid never spill, and a wave alone on its SIMD no longer waits for the memory
+// round trips of the spill / reload paths.  The geometry is then a run-time value (three more integer registers).
+template <typename R, bool NARROW>
 struct DtRing {
     static constexpr int kSlotBytes = 64 * (2 * (int)sizeof(R) + 4);
-    char *zs;                     // this lane's z of slot 0 (s is 64 R further)
+    char *zs;                     // this lane's z of slot 0 (s is 64 (L) R further)
     char *vp;                     // this lane's v of slot 0
     StkPairT<R> *g;               // this lane's column of the global [pair][lane] stack
     double a, b;                  // the job's quadratic (z of the upper entry of a reloaded pair)
     int lo;                       // ring holds indices [lo, top); lo is even; entries below lo are spilled
-    __device__ __forceinline__ R &z(int slot) { return *reinterpret_cast<R *>(zs + slot * kSlotBytes); }
-    __device__ __forceinline__ R &s(int slot) { return *reinterpret_cast<R *>(zs + slot * kSlotBytes + 64 * (int)sizeof(R)); }
-    __device__ __forceinline__ int &v(int slot) { return *reinterpret_cast<int *>(vp + slot * kSlotBytes); }
+    int tmask, sbytes, soff;      // NARROW: entries - 1, bytes per slot, byte offset of s behind z
+    __device__ __forceinline__ int T() const { return NARROW ? tmask + 1 : kDtT; }
+    __device__ __forceinline__ int slot_of(int idx) const { return NARROW ? (idx & tmask) : (idx & (kDtT - 1)); }
+    __device__ __forceinline__ int off(int slot) const { return NARROW ? slot * sbytes : slot * kSlotBytes; }
+    __device__ __forceinline__ R &z(int slot) { return *reinterpret_cast<R *>(zs + off(slot)); }
+    __device__ __forceinline__ R &s(int slot) { return *reinterpret_cast<R *>(zs + off(slot) + (NARROW ? soff : 64 * (int)sizeof(R))); }
+    __device__ __forceinline__ int &v(int slot) { return *reinterpret_cast<int *>(vp + off(slot)); }
     __device__ __forceinline__ void push_below(int idx, R zk, R sk, int vk)
     {   // entry `idx` (the old top) moves under a new top
-        const int slot = idx & (kDtT - 1);
-        if (idx - lo >= kDtT) {   // ring full: spill its two oldest entries lo, lo + 1 as one record
+        const int slot = slot_of(idx);
+        if (idx - lo >= T()) {   // ring full: spill its two oldest entries lo, lo + 1 as one record
             DT_STAT(3);
-            const int sl = lo & (kDtT - 1);
+            const int sl = slot_of(lo);
             g[(size_t)(lo >> 1) * 64] = StkPairT<R>{s(sl), s(sl + 1), z(sl), (unsigned)v(sl) | ((unsigned)v(sl + 1) << 16)};
             lo += 2;
         }
@@ -130,7 +138,7 @@ struct DtRing {
     {   // entry `idx` becomes the top
         // the ring slot is read unconditionally (always a valid LDS address) so that the common case is
         // plain LDS reads; only a pop below the ring overrides it from the spill stack
-        const int slot = idx & (kDtT - 1);
+        const int slot = slot_of(idx);
         zk = z(slot); sk = s(slot); vk = v(slot);
         asm volatile("" : "+v"(zk), "+v"(sk), "+v"(vk));   // keep these as LDS reads (not a flat load of a selected pointer)
         if (idx < lo) {
@@ -139,18 +147,19 @@ struct DtRing {
             // into the ring, the upper one is the new top and gets its z recomputed
             const StkPairT<R> e = g[(size_t)((lo - 2) >> 1) * 64];
             const int va = (int)(e.vv & 0xffffu), vb = (int)(e.vv >> 16);
-            const int sl = (lo - 2) & (kDtT - 1);
+            const int sl = slot_of(lo - 2);
             z(sl) = e.za; s(sl) = e.sa; v(sl) = va;
             sk = e.sb; vk = vb;
             zk = BZ ? quad_isect<R, true>(a, b, va, vb, e.sa, e.sb) : quad_isect<R, false>(a, b, va, vb, e.sa, e.sb);   // as computed when entry lo-1 was pushed onto entry lo-2
             lo -= 2;
         }
     }
-    // the ring of wave `w` of the workgroup inside `smem`
-    static __device__ __forceinline__ DtRing make(char *smem, int w, int lane, StkPairT<R> *g, double a, double b)
+    // the ring of the workgroup's wave inside `smem`; `lanep` = the lane's number inside the wave, sh = lane_shift
+    static __device__ __forceinline__ DtRing make(char *smem, int lanep, int sh, StkPairT<R> *g, double a, double b)
     {
-        char *base = smem + (size_t)w * kDtT * kSlotBytes;
-        return DtRing{base + lane * (int)sizeof(R), base + 128 * (int)sizeof(R) + lane * 4, g, a, b, 0};
+        const int L = NARROW ? (64 >> sh) : 64;
+        return DtRing{smem + lanep * (int)sizeof(R), smem + 2 * L * (int)sizeof(R) + lanep * 4, g, a, b, 0,
+                      (kDtT << (NARROW ? sh : 0)) - 1, L * (2 * (int)sizeof(R) + 4), L * (int)sizeof(R)};
     }
 };
 
@@ -172,8 +181,8 @@ template <int EPW> __device__ __forceinline__ void dt_put(int *w, int i, int v) 
 
 // AUX: the read-out additionally streams an int chunk per output chunk (prefetched one chunk ahead, q
 // descending) and hands it to `store` -- the columns pass uses it to carry the rows pass's pointers along.
-template <typename R, bool AUX, bool BZ, int CH, int EPW, class LoadChunk, class StoreChunk, class AuxChunk>
-__device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R> ring, LoadChunk load, StoreChunk store,
+template <typename R, bool AUX, bool BZ, int CH, int EPW, bool NARROW, class LoadChunk, class StoreChunk, class AuxChunk>
+__device__ __forceinline__ void dt_stream(int N, double a, double b, int os0, DtRing<R, NARROW> ring, LoadChunk load, StoreChunk store,
                                           AuxChunk aux)
 {
     R cur[CH], nxt[CH];
@@ -251,7 +260,7 @@ static_assert(kDtCHC % 8 == 0 && kDtCH % 8 == 0, "int16 pointers and fp16 respon
 // ---- rows pass: thread = (flat row, job, frame); each lane streams its own row with 16-byte accesses ----
 // RH: the responses are fp16 (PBD_CONV_MFMA_F16); a template parameter so that the default kernels carry none of it
 // PT: element type of the position planes (uint8_t when no map side exceeds 256, else int16_t)
-template <typename R, bool RH, typename PT, bool BZ>
+template <typename R, bool RH, typename PT, bool BZ, bool NARROW>
 __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
 {
     constexpr int EPW = 4 / (int)sizeof(PT);
@@ -291,8 +300,8 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     const size_t jb = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
     R *tmpT = static_cast<R *>(p.tmp) + jb + (size_t)y;
     PT *ixT = static_cast<PT *>(p.IxRaw) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + (size_t)y;
-    __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
-    DtRing<R> ring = DtRing<R>::make(ring_mem, 0, lanep,
+    __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R, NARROW>::kSlotBytes];
+    DtRing<R, NARROW> ring = DtRing<R, NARROW>::make(ring_mem, lanep, sh,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
                                          ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_row_off[wv]) + lane, job.ax, job.bx);
     const int N = active ? W : 0;
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
         }
     };
     auto noaux = [](int, int *) {};
-    dt_stream<R, false, BZ, kDtCH, EPW>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
+    dt_stream<R, false, BZ, kDtCH, EPW, NARROW>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
 }
 
 // Rows (columns) per wave of a pass: 64 when the launch fills the chip (1024 SIMDs), else 32 .. 4 -- see k_dt_rows.
@@ -355,9 +364,10 @@ void launch_dt_rows(const DpParams &p0, int nframes, bool f64, hipStream_t s)
     dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_ROWS(PT, BZ)                                                                                              \
     do {                                                                                                              \
-        if (f64) PBD_LAUNCH((k_dt_rows<double, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);          \
-        else if (p.resp_half) PBD_LAUNCH((k_dt_rows<float, true, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p); \
-        else PBD_LAUNCH((k_dt_rows<float, false, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);               \
+        if (f64) PBD_LAUNCH((k_dt_rows<double, false, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);          \
+        else if (p.resp_half) PBD_LAUNCH((k_dt_rows<float, true, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p); \
+        else if (p.lane_shift > 0) PBD_LAUNCH((k_dt_rows<float, false, PT, BZ, true>), grid, dim3(64 * kDtWaves), 0, s, p); \
+        else PBD_LAUNCH((k_dt_rows<float, false, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);               \
     } while (0)
     if (p.ptr8) { if (p.bz_x) PBD_ROWS(uint8_t, true); else PBD_ROWS(uint8_t, false); }
     else { if (p.bz_x) PBD_ROWS(int16_t, true); else PBD_ROWS(int16_t, false); }
@@ -365,8 +375,8 @@ void launch_dt_rows(const DpParams &p0, int nframes, bool f64, hipStream_t s)
 }
 
 // ---- columns pass: thread = (flat column, job, frame); lanes are adjacent columns -> coalesced ----
-template <typename R, typename PT, bool BZ>
-__global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? (sizeof(PT) == 1 ? 6 : 5) : 1)))
+template <typename R, typename PT, bool BZ, bool NARROW>
+__global__ __launch_bounds__(64 * kDtWaves) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? (sizeof(PT) == 1 && !NARROW ? 6 : 5) : 1)))
 void k_dt_cols(DpParams p)
 {
     constexpr int EPW = 4 / (int)sizeof(PT);
@@ -386,8 +396,8 @@ void k_dt_cols(DpParams p)
     const R *tmpT = static_cast<const R *>(p.tmp) + jbase + (size_t)x * H;     // this lane's column, contiguous
     R *dt = static_cast<R *>(p.dt) + jbase + x;
     PT *iyr = static_cast<PT *>(p.IyRaw) + ((size_t)(p.frame0 + fl) * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + x;
-    __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R>::kSlotBytes];
-    DtRing<R> ring = DtRing<R>::make(ring_mem, 0, lanep,
+    __shared__ __attribute__((aligned(16))) char ring_mem[kDtWaves * kDtT * DtRing<R, NARROW>::kSlotBytes];
+    DtRing<R, NARROW> ring = DtRing<R, NARROW>::make(ring_mem, lanep, sh,
                                      reinterpret_cast<StkPairT<R> *>(p.stk) +
                                          ((size_t)(fl * p.JG + j) * p.stk_per_jf + p.stk_col_off[wv]) + lane, job.ay, job.by);
     auto load = [&](int q0, R *buf) {
@@ -416,7 +426,7 @@ void k_dt_cols(DpParams p)
             dp += W; yp += W;
         }
     };
-    dt_stream<R, false, BZ, kDtCHC, EPW>(H, job.ay, job.by, job.osy, ring, load, store, noaux);
+    dt_stream<R, false, BZ, kDtCHC, EPW, NARROW>(H, job.ay, job.by, job.osy, ring, load, store, noaux);
 }
 
 void launch_dt_cols(const DpParams &p0, int nframes, bool f64, hipStream_t s)
@@ -428,8 +438,9 @@ void launch_dt_cols(const DpParams &p0, int nframes, bool f64, hipStream_t s)
     dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_COLS(PT, BZ)                                                                                   \
     do {                                                                                                   \
-        if (f64) PBD_LAUNCH((k_dt_cols<double, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);      \
-        else PBD_LAUNCH((k_dt_cols<float, PT, BZ>), grid, dim3(64 * kDtWaves), 0, s, p);           \
+        if (f64) PBD_LAUNCH((k_dt_cols<double, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);      \
+        else if (p.lane_shift > 0) PBD_LAUNCH((k_dt_cols<float, PT, BZ, true>), grid, dim3(64 * kDtWaves), 0, s, p); \
+        else PBD_LAUNCH((k_dt_cols<float, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);           \
     } while (0)
     if (p.ptr8) { if (p.bz_y) PBD_COLS(uint8_t, true); else PBD_COLS(uint8_t, false); }
     else { if (p.bz_y) PBD_COLS(int16_t, true); else PBD_COLS(int16_t, false); }
