@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     constexpr int EPW = 4 / (int)sizeof(PT);
     // grid = (job, frame, wave of 64 flat rows): the wave index is the SLOWEST dimension, so the long rows of
     // the large levels are dispatched first and the tail of the launch is made of short ones
-    // lane_shift (0 .. 4): a group of 64 flat rows is spread over 1 .. 16 waves that use their first 64 .. 4 lanes only.
+    // lane_shift (0 .. 6): a group of 64 flat rows is spread over 1 .. 64 waves that use their first 64 .. 1 lanes only.
     // A launch that does not fill the chip anyway (one frame, a few 1080p frames) then runs as more, narrower waves: the wave's
     // pop loops iterate for the slowest of 16 lanes instead of 64, and the launch takes what its longest rows take (launch_dt_rows).
     static_assert(kDtWaves == 1, "one wave per workgroup");
@@ -345,13 +345,13 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     dt_stream<R, false, BZ, kDtCH, EPW, NARROW>(N, job.ax, job.bx, job.osx, ring, load, store, noaux);
 }
 
-// Rows (columns) per wave of a pass: 64 when the launch fills the chip (1024 SIMDs), else 32 .. 4 -- see k_dt_rows.
+// Rows (columns) per wave of a pass: 64 when the launch fills the chip (1024 SIMDs), else 32 .. 1 -- see k_dt_rows.
 static int dt_lane_shift(long long waves64)
 {
     static const int forced = getenv("PBD_DT_LANESHIFT") ? atoi(getenv("PBD_DT_LANESHIFT")) : -1;
-    if (forced >= 0 && forced <= 4) return forced;
+    if (forced >= 0 && forced <= 6) return forced;
     int sh = 0;
-    while (sh < 4 && (waves64 << (sh + 1)) <= 6144) ++sh;       // at most one round of waves (six per SIMD)
+    while (sh < 6 && (waves64 << (sh + 1)) <= 6144) ++sh;       // at most one round of waves (six per SIMD)
     return sh;
 }
 

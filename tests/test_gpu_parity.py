@@ -848,7 +848,7 @@ def test_fused_path_responses_every_level(det_mod, oracle):
 def test_narrow_wave_distance_transform(det_mod, oracle):
     """Launches of the distance-transform passes that do not fill the chip run as more, narrower waves (64 >> lane_shift rows
     per wave, chosen per launch: pbd_kernels_dp.hip, dt_lane_shift).  The rows' arithmetic is untouched, so every setting must
-    give the oracle's candidates: each of 64 / 32 / 16 / 8 / 4 rows per wave is forced in a fresh interpreter
+    give the oracle's candidates: each of 64 / 32 / 16 / 8 / 4 / 2 / 1 rows per wave is forced in a fresh interpreter
     (PBD_DT_LANESHIFT is read once per process) on a frame with rows of up to 78 cells and int16-free uint8 planes, and once
     on a frame wide enough for int16 planes."""
     import hashlib, json, os, subprocess, sys
@@ -869,7 +869,7 @@ def test_narrow_wave_distance_transform(det_mod, oracle):
         "    det.hd.close()\n"
         "print(json.dumps(out))\n" % root)
     results = {}
-    for shift in ("auto", "0", "1", "2", "3", "4"):
+    for shift in ("auto", "0", "1", "2", "3", "4", "5", "6"):
         env = dict(os.environ)
         env.pop("PBD_DT_LANESHIFT", None)
         if shift != "auto":
