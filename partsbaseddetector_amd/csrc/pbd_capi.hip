@@ -111,6 +111,7 @@ struct Plan {
     int interval = 0;
     int nrows_flat = 0, ncols_flat = 0;
     bool ptr8 = false;              // no feature map side exceeds 256: positions fit uint8 (back-pointer planes at half the bytes)
+    int longest = 0;                // longest side of any feature map of the plan (rows / columns of the distance transform)
     int ntiles = 0;
     // device tables
     DevTable<LevelDesc> d_lv;
@@ -419,6 +420,7 @@ hipError_t finish_plan_tables(Plan &P, int sbin)
         int longest = 0;
         for (const LevelDesc &d : P.lv) longest = std::max(longest, std::max(d.rows, d.cols));
         P.ptr8 = longest <= 256;
+        P.longest = longest;
     }
     rowoff[P.nlevels] = (int)row2level.size();
     coloff[P.nlevels] = (int)col2level.size();
@@ -1222,7 +1224,7 @@ void launch_dp_chunk(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
     dp.stk_row_off = P.d_stk_row_off.d; dp.stk_col_off = P.d_stk_col_off.d;
     dp.biasw = h->d_biasw.d;
     dp.row2level = P.d_row2level.d; dp.rowoff = P.d_rowoff.d; dp.col2level = P.d_col2level.d; dp.coloff = P.d_coloff.d;
-    dp.nrows_flat = P.nrows_flat; dp.ncols_flat = P.ncols_flat;
+    dp.nrows_flat = P.nrows_flat; dp.ncols_flat = P.ncols_flat; dp.longest = P.longest;
     dp.rootv = h->rootv.p; dp.rooti = h->rooti.as<int>(); dp.rjobs = h->d_rjobs.d;
     dp.frame0 = f0;
     for (auto &g : h->groups) {

@@ -223,6 +223,7 @@ struct DpParams {
     const int *row2level; const int *rowoff;   // flat row -> level, level -> first flat row
     const int *col2level; const int *coloff;
     int nrows_flat, ncols_flat;
+    int longest;                  // longest row / column of the plan (LDS of the cooperative passes)
     void *rootv; int *rooti;      // R / int [frames][cell_per_frame*NC]
     const RootJob *rjobs;
 };

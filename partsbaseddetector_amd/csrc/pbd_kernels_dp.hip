@@ -355,12 +355,17 @@ static int dt_lane_shift(long long waves64)
     return sh;
 }
 
+template <bool COLS> static void launch_dt_coop(const DpParams &p, int nframes, int nflat, bool bz, hipStream_t s);
+static bool dt_coop_enabled(int longest);
+static int dt_coop_min_shift();
+
 void launch_dt_rows(const DpParams &p0, int nframes, bool f64, hipStream_t s)
 {
     if (p0.JG == 0 || p0.nrows_flat == 0) return;
     const int nwv = (p0.nrows_flat + 63) / 64;
     DpParams p = p0;
     p.lane_shift = dt_lane_shift((long long)p.JG * nframes * nwv);
+    if (p.lane_shift >= dt_coop_min_shift() && !f64 && !p.resp_half && dt_coop_enabled(p.longest)) { launch_dt_coop<false>(p, nframes, p.nrows_flat, p.bz_x != 0, s); return; }
     dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_ROWS(PT, BZ)                                                                                              \
     do {                                                                                                              \
@@ -435,6 +440,7 @@ void launch_dt_cols(const DpParams &p0, int nframes, bool f64, hipStream_t s)
     const int nwv = (p0.ncols_flat + 63) / 64;
     DpParams p = p0;
     p.lane_shift = dt_lane_shift((long long)p.JG * nframes * nwv);
+    if (p.lane_shift >= dt_coop_min_shift() && !f64 && dt_coop_enabled(p.longest)) { launch_dt_coop<true>(p, nframes, p.ncols_flat, p.bz_y != 0, s); return; }
     dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_COLS(PT, BZ)                                                                                   \
     do {                                                                                                   \
@@ -445,6 +451,157 @@ void launch_dt_cols(const DpParams &p0, int nframes, bool f64, hipStream_t s)
     if (p.ptr8) { if (p.bz_y) PBD_COLS(uint8_t, true); else PBD_COLS(uint8_t, false); }
     else { if (p.bz_y) PBD_COLS(int16_t, true); else PBD_COLS(int16_t, false); }
 #undef PBD_COLS
+}
+
+// ---- wavefront-cooperative form of a pass: FOUR rows (columns) per wave, sixteen lanes each --------------------------------
+// For launches of so few rows that narrow waves of eight lanes or fewer would be used (one frame: lane_shift >= 3).  A narrow wave is
+// bound by the number of instructions it issues, and three quarters of the lanes of a four-row wave do nothing; here a row's
+// sixteen lanes hold the TOP SIXTEEN entries of its envelope (entry e in lane e & 15 while e is in the aligned block of the
+// top; every entry is also written through to LDS, from where a lower block is fetched back when the whole window is popped).
+// Inserting element q evaluates the reference's pop predicate -- s(v[e], q) <= z[e] && e > 0, the same expression on the same
+// operands -- for all window entries AT ONCE; the sequential loop pops from the top until the first entry whose predicate is
+// false, i.e. the new top is the highest entry that stays (ballot + find-first-bit) and the pushed z is that entry's
+// intersection.  No pop loop, no divergence: ~60 instructions per element for four rows, whatever the data.  The read-out is
+// a binary search of the (increasing) z of the finished envelope in LDS for sixteen positions of a row at a time:
+// max{k : z[k] < os + q}, what the reference's "while (z[k+1] < os) k++" selects.  Outputs as in the plain passes.
+// G rows per wave, W = 64 / G lanes each (G = 4: window of 16 entries; G = 8: window of 8 -- half the waves for launches that
+// would otherwise need more than one round of them, at the price of more fetches of a lower block)
+template <bool BZ, typename PT, bool COLS, int G>
+__global__ __launch_bounds__(64) void k_dt_coop(DpParams p)
+{
+    constexpr int kCoopRows = G, kCoopW = 64 / G, kCoopLog = (G == 4 ? 4 : 3);
+    static_assert(G == 4 || G == 8, "four or eight rows per wave");
+    extern __shared__ __attribute__((aligned(16))) char coop_mem[];
+    const int lanep = threadIdx.x, grp = lanep >> kCoopLog, sub = lanep & (kCoopW - 1), gl0 = grp << kCoopLog;
+    const int nflat = COLS ? p.ncols_flat : p.nrows_flat;
+    const int r = (int)blockIdx.z * kCoopRows + grp;
+    const bool active = r < nflat;
+    const int rr = active ? r : nflat - 1;
+    const int j = blockIdx.x, fl = blockIdx.y, frame = p.frame0 + fl;
+    const int l = (COLS ? p.col2level : p.row2level)[rr];
+    const LevelDesc d = p.lv[l];
+    const int idx = rr - (COLS ? p.coloff : p.rowoff)[l];          // y of the row / x of the column
+    const int H = d.rows, W = d.cols;
+    const size_t HW = (size_t)H * W;
+    const DtJob job = p.jobs[j];
+    const int N = active ? (COLS ? H : W) : 0;
+    const double a = COLS ? job.ay : job.ax, b = COLS ? job.by : job.bx;
+    const int os0 = COLS ? job.osy : job.osx;
+    const size_t jb = ((size_t)fl * p.cell_per_frame + d.cell_off) * p.JG + (size_t)j * HW;
+    const float *src;
+    if (COLS) src = static_cast<const float *>(p.tmp) + jb + (size_t)idx * H;
+    else src = (job.from_acc ? static_cast<const float *>(p.acc) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NM
+                             : static_cast<const float *>(p.resp) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.F) +
+               (size_t)job.plane * HW + (size_t)idx * W;
+    // outputs: element q at out + q * ostr (rows pass: transposed planes [x][y]; columns pass: [y][x])
+    const int ostr = COLS ? W : H;
+    float *outv = (COLS ? static_cast<float *>(p.dt) : static_cast<float *>(p.tmp)) + jb + idx;
+    PT *outp = static_cast<PT *>(COLS ? p.IyRaw : p.IxRaw) + ((size_t)frame * p.cell_per_frame + d.cell_off) * p.NJ + (size_t)job.gm * HW + idx;
+    const int maxn = p.longest;
+    float *zs = reinterpret_cast<float *>(coop_mem) + (size_t)grp * 3 * maxn, *ys = zs + maxn;
+    int *vs = reinterpret_cast<int *>(ys + maxn);
+    int nm = N;
+#pragma unroll
+    for (int o = kCoopW; o < 64; o <<= 1) nm = max(nm, __shfl_xor(nm, o));
+    const int Nmax = __builtin_amdgcn_readfirstlane(nm);
+    if (Nmax == 0) return;
+
+    // ---- scan: the envelope of the row, top block in registers (this lane: entry wbase + sub), all of it in LDS.
+    // Two values cross lanes per element -- the element itself and the new top's intersection -- and each is requested a step
+    // before it is needed: the element of step i + 1 at the start of step i, and the z of the entry pushed in step i is held
+    // as (pl, pz) and merged into the window at the NEXT step's compare (its v and y, which the next intersection needs, are
+    // set at once), so that no step waits for its own cross-lane read.
+    float cur = (sub < N) ? src[sub] : 0.0f;
+    float ez = -INFINITY, ey = __shfl(cur, gl0);
+    int ev = 0, k = 0, wbase = 0;
+    int pl = -1;                 // lane (of the row) whose z is still pending, -1: none
+    float pz = 0.0f;
+    int pk = 0;                  // ... and its entry index (LDS write-through of z)
+    if (sub == 0 && N > 0) { zs[0] = ez; ys[0] = ey; vs[0] = 0; }
+    for (int q0 = 0; q0 < Nmax; q0 += kCoopW) {
+        const float nxt = (q0 + kCoopW + sub < N) ? src[q0 + kCoopW + sub] : 0.0f;
+        const int i0 = (q0 == 0 ? 1 : 0);
+        float yq = __shfl(cur, gl0 + i0);
+        for (int i = i0; i < kCoopW && q0 + i < Nmax; ++i) {
+            const int q = q0 + i;
+            const bool rowact = q < N;
+            const float ynext = __shfl(cur, gl0 + ((i + 1) & (kCoopW - 1)));      // next step's element (unused after the chunk's last)
+            float s;
+            unsigned m;
+            for (;;) {
+                const int e = wbase + sub;
+                s = quad_isect<float, BZ>(a, b, ev, q, ey, yq);
+                if (sub == pl) { ez = pz; zs[pk] = pz; }                           // the pending z arrives here
+                pl = -1;
+                const bool stay = rowact && e <= k && !((s <= ez) && e > 0);      // entry 0 always stays (the reference's k > 0)
+                m = (unsigned)(__ballot(stay) >> gl0) & ((1u << kCoopW) - 1u);
+                const bool lower = rowact && m == 0;       // the whole window is popped: the top moves into the block below
+                if (!__any(lower)) break;
+                if (lower) { wbase -= kCoopW; k = wbase + kCoopW - 1; ez = zs[wbase + sub]; ey = ys[wbase + sub]; ev = vs[wbase + sub]; }
+            }
+            const int top = wbase + (rowact ? 31 - __clz((int)m) : 0);     // the highest entry that stays
+            pz = __shfl(s, gl0 + (top & (kCoopW - 1)));                     // its intersection with q: z of the pushed entry
+            if (rowact) {
+                k = top + 1;
+                if ((k & (kCoopW - 1)) == 0) wbase = k;                      // the pushed entry opens a new block
+                pl = k & (kCoopW - 1); pk = k;
+                if (sub == pl) { ev = q; ey = yq; ys[k] = yq; vs[k] = q; }
+            }
+            yq = ynext;
+        }
+        cur = nxt;
+    }
+    if (sub == pl) { ez = pz; zs[pk] = pz; }                                 // the last pushed entry's z
+    // ---- read-out: sixteen positions of the row at a time
+    for (int p0 = 0; p0 < Nmax; p0 += kCoopW) {
+        const int pq = p0 + sub;
+        const float osf = (float)(os0 + pq);
+        int lo = 0, hi = k;
+        while (__any(lo < hi)) {
+            const int mid = (lo + hi + 1) >> 1;
+            const bool lt = zs[mid] < osf;
+            if (lo < hi) { if (lt) lo = mid; else hi = mid - 1; }
+        }
+        if (pq < N) {
+            outv[(size_t)pq * ostr] = quad_val<float, BZ>(a, b, os0 + pq - vs[lo], ys[lo]);
+            outp[(size_t)pq * ostr] = (PT)vs[lo];
+        }
+    }
+}
+
+// launches that would run with 8 or fewer rows per wave go to the cooperative kernel (measured, one 640x480 frame: from 4 rows
+// per wave on 2.49 ms, from 8 on 2.37, from 16 on 2.43; a 1080p frame gets slower from 16 on: more waves than the chip holds)
+static int dt_coop_min_shift() { return 3; }
+static bool dt_coop_enabled(int longest)
+{
+    static const int v = getenv("PBD_DT_COOP") ? atoi(getenv("PBD_DT_COOP")) : 1;
+    // the envelopes of a wave's rows live in LDS (12 bytes per element): beyond 12 KB per wave too few waves fit a CU (a
+    // 1080p frame with four rows per wave: 23 KB, and its single-frame rate fell from 83 to 69 detections/s)
+    return v != 0 && (size_t)4 * 3 * longest * sizeof(float) <= (size_t)12 * 1024;
+}
+
+template <bool COLS, int G>
+static void launch_dt_coop_g(const DpParams &p, int nframes, int nflat, bool bz, hipStream_t s)
+{
+    dim3 grid(p.JG, nframes, (nflat + G - 1) / G);
+    const unsigned lds = (unsigned)((size_t)G * 3 * p.longest * sizeof(float));
+    if (p.ptr8) {
+        if (bz) PBD_LAUNCH((k_dt_coop<true, uint8_t, COLS, G>), grid, dim3(64), lds, s, p);
+        else PBD_LAUNCH((k_dt_coop<false, uint8_t, COLS, G>), grid, dim3(64), lds, s, p);
+    } else {
+        if (bz) PBD_LAUNCH((k_dt_coop<true, int16_t, COLS, G>), grid, dim3(64), lds, s, p);
+        else PBD_LAUNCH((k_dt_coop<false, int16_t, COLS, G>), grid, dim3(64), lds, s, p);
+    }
+}
+template <bool COLS>
+static void launch_dt_coop(const DpParams &p, int nframes, int nflat, bool bz, hipStream_t s)
+{
+    // four rows per wave while that stays within one round of waves, else eight
+    static const int forced = getenv("PBD_DT_COOP_G") ? atoi(getenv("PBD_DT_COOP_G")) : 0;
+    const long long waves4 = (long long)p.JG * nframes * ((nflat + 3) / 4);
+    const bool g8 = forced ? forced == 8 : (waves4 > 6144 && (size_t)8 * 3 * p.longest * sizeof(float) <= (size_t)12 * 1024);
+    if (g8) launch_dt_coop_g<COLS, 8>(p, nframes, nflat, bz, s);
+    else launch_dt_coop_g<COLS, 4>(p, nframes, nflat, bz, s);
 }
 
 // ---- combine: thread = 4 consecutive cells of one level, one PARENT part (block.y) ---------------------

@@ -869,14 +869,22 @@ def test_narrow_wave_distance_transform(det_mod, oracle):
         "    det.hd.close()\n"
         "print(json.dumps(out))\n" % root)
     results = {}
-    for shift in ("auto", "0", "1", "2", "3", "4", "5", "6"):
+    # launches with eight or fewer rows per wave (lane_shift >= 3) go to the wavefront-cooperative kernel k_dt_coop (four rows
+    # per wave, sixteen lanes each holding the envelope's top block) unless PBD_DT_COOP=0: both forms are forced
+    for shift, coop in [("auto", None), ("0", None), ("1", None), ("2", None), ("3", None), ("4", None), ("5", None), ("6", None),
+                        ("3", "0"), ("4", "0"), ("6", "0"), ("4", "g8")]:
         env = dict(os.environ)
-        env.pop("PBD_DT_LANESHIFT", None)
+        for k_ in ("PBD_DT_LANESHIFT", "PBD_DT_COOP", "PBD_DT_COOP_G"):
+            env.pop(k_, None)
         if shift != "auto":
             env["PBD_DT_LANESHIFT"] = shift
+        if coop == "g8":
+            env["PBD_DT_COOP_G"] = "8"                  # eight rows per wave (windows of eight entries)
+        elif coop is not None:
+            env["PBD_DT_COOP"] = coop
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
-        results[shift] = json.loads(r.stdout.strip().splitlines()[-1])
+        results[shift + ("" if coop is None else "/coop" + coop)] = json.loads(r.stdout.strip().splitlines()[-1])
     assert all(v == results["0"] for v in results.values()), results
     assert results["0"]["u8"][0] > 10 and results["0"]["i16"][0] > 10
     # and the 64-rows-per-wave result is the oracle's
