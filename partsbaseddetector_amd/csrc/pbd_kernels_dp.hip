@@ -365,7 +365,7 @@ void launch_dt_rows(const DpParams &p0, int nframes, bool f64, hipStream_t s)
     const int nwv = (p0.nrows_flat + 63) / 64;
     DpParams p = p0;
     p.lane_shift = dt_lane_shift((long long)p.JG * nframes * nwv);
-    if (p.lane_shift >= dt_coop_min_shift() && !f64 && !p.resp_half && dt_coop_enabled(p.longest)) { launch_dt_coop<false>(p, nframes, p.nrows_flat, p.bz_x != 0, s); return; }
+    if (p.lane_shift >= dt_coop_min_shift() && !f64 && !p.resp_half && p.ptr8 && dt_coop_enabled(p.longest)) { launch_dt_coop<false>(p, nframes, p.nrows_flat, p.bz_x != 0, s); return; }
     dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_ROWS(PT, BZ)                                                                                              \
     do {                                                                                                              \
@@ -440,7 +440,7 @@ void launch_dt_cols(const DpParams &p0, int nframes, bool f64, hipStream_t s)
     const int nwv = (p0.ncols_flat + 63) / 64;
     DpParams p = p0;
     p.lane_shift = dt_lane_shift((long long)p.JG * nframes * nwv);
-    if (p.lane_shift >= dt_coop_min_shift() && !f64 && dt_coop_enabled(p.longest)) { launch_dt_coop<true>(p, nframes, p.ncols_flat, p.bz_y != 0, s); return; }
+    if (p.lane_shift >= dt_coop_min_shift() && !f64 && p.ptr8 && dt_coop_enabled(p.longest)) { launch_dt_coop<true>(p, nframes, p.ncols_flat, p.bz_y != 0, s); return; }
     dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_COLS(PT, BZ)                                                                                   \
     do {                                                                                                   \
@@ -585,13 +585,9 @@ static void launch_dt_coop_g(const DpParams &p, int nframes, int nflat, bool bz,
 {
     dim3 grid(p.JG, nframes, (nflat + G - 1) / G);
     const unsigned lds = (unsigned)((size_t)G * 3 * p.longest * sizeof(float));
-    if (p.ptr8) {
-        if (bz) PBD_LAUNCH((k_dt_coop<true, uint8_t, COLS, G>), grid, dim3(64), lds, s, p);
-        else PBD_LAUNCH((k_dt_coop<false, uint8_t, COLS, G>), grid, dim3(64), lds, s, p);
-    } else {
-        if (bz) PBD_LAUNCH((k_dt_coop<true, int16_t, COLS, G>), grid, dim3(64), lds, s, p);
-        else PBD_LAUNCH((k_dt_coop<false, int16_t, COLS, G>), grid, dim3(64), lds, s, p);
-    }
+    // (rows of at most 256 elements: the position planes are uint8 -- dt_coop_enabled)
+    if (bz) PBD_LAUNCH((k_dt_coop<true, uint8_t, COLS, G>), grid, dim3(64), lds, s, p);
+    else PBD_LAUNCH((k_dt_coop<false, uint8_t, COLS, G>), grid, dim3(64), lds, s, p);
 }
 template <bool COLS>
 static void launch_dt_coop(const DpParams &p, int nframes, int nflat, bool bz, hipStream_t s)
