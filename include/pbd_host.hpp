@@ -557,7 +557,12 @@ public:
     FrameStream(Model &model, int nhandles = 4, int device = 0, int capacity = 1 << 16) : submitted_(0), collected_(0), capacity_(capacity)
     {
         if (nhandles < 1) throw Error(PBD_ERR_INVALID, "FrameStream needs at least one handle");
-        for (int i = 0; i < nhandles; ++i) h_.push_back(pbdbind::create<HostTraits<T> >(model, device, PBD_CONV_EXACT, 1, capacity));
+        try {
+            for (int i = 0; i < nhandles; ++i) h_.push_back(pbdbind::create<HostTraits<T> >(model, device, PBD_CONV_EXACT, 1, capacity));
+        } catch (...) {      // a later handle failed (out of memory): the earlier ones must not leak
+            for (size_t i = 0; i < h_.size(); ++i) pbd_destroy(h_[i]);
+            throw;
+        }
     }
     ~FrameStream() { for (size_t i = 0; i < h_.size(); ++i) pbd_destroy(h_[i]); }
     size_t pending() const { return submitted_ - collected_; }

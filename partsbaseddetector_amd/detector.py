@@ -413,10 +413,14 @@ class DetectorPool:
         if n < 1:
             raise ValueError("DetectorPool needs at least one detector")
         self.dets: List[PartsBasedDetector] = []
-        for _ in range(n):
-            d = PartsBasedDetector(**kw)
-            d.distributeModel(model)
-            self.dets.append(d)
+        try:
+            for _ in range(n):
+                d = PartsBasedDetector(**kw)
+                d.distributeModel(model)
+                self.dets.append(d)
+        except Exception:           # a later handle failed (e.g. out of memory): release the earlier ones
+            self.close()
+            raise
         self._submitted = 0         # batches submitted so far
         self._collected = 0         # batches handed back so far
 
