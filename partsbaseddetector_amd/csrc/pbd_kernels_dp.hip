@@ -506,33 +506,24 @@ __global__ __launch_bounds__(64) void k_dt_coop(DpParams p)
     const int Nmax = __builtin_amdgcn_readfirstlane(nm);
     if (Nmax == 0) return;
 
-    // ---- scan: the envelope of the row, top block in registers (this lane: entry wbase + sub), all of it in LDS.
-    // Two values cross lanes per element -- the element itself and the new top's intersection -- and each is requested a step
-    // before it is needed: the element of step i + 1 at the start of step i, and the z of the entry pushed in step i is held
-    // as (pl, pz) and merged into the window at the NEXT step's compare (its v and y, which the next intersection needs, are
-    // set at once), so that no step waits for its own cross-lane read.
+    // ---- scan: the envelope of the row, top block in registers (this lane: entry wbase + sub), all of it in LDS
+    // (requesting the step's two cross-lane values -- the element, the pushed entry's z -- one step early was measured and
+    // changed nothing: the kernel is bound by the instructions it issues, not by the latency of these reads)
     float cur = (sub < N) ? src[sub] : 0.0f;
     float ez = -INFINITY, ey = __shfl(cur, gl0);
     int ev = 0, k = 0, wbase = 0;
-    int pl = -1;                 // lane (of the row) whose z is still pending, -1: none
-    float pz = 0.0f;
-    int pk = 0;                  // ... and its entry index (LDS write-through of z)
     if (sub == 0 && N > 0) { zs[0] = ez; ys[0] = ey; vs[0] = 0; }
     for (int q0 = 0; q0 < Nmax; q0 += kCoopW) {
         const float nxt = (q0 + kCoopW + sub < N) ? src[q0 + kCoopW + sub] : 0.0f;
-        const int i0 = (q0 == 0 ? 1 : 0);
-        float yq = __shfl(cur, gl0 + i0);
-        for (int i = i0; i < kCoopW && q0 + i < Nmax; ++i) {
+        for (int i = (q0 == 0 ? 1 : 0); i < kCoopW && q0 + i < Nmax; ++i) {
             const int q = q0 + i;
             const bool rowact = q < N;
-            const float ynext = __shfl(cur, gl0 + ((i + 1) & (kCoopW - 1)));      // next step's element (unused after the chunk's last)
+            const float yq = __shfl(cur, gl0 + i);
             float s;
             unsigned m;
             for (;;) {
                 const int e = wbase + sub;
                 s = quad_isect<float, BZ>(a, b, ev, q, ey, yq);
-                if (sub == pl) { ez = pz; zs[pk] = pz; }                           // the pending z arrives here
-                pl = -1;
                 const bool stay = rowact && e <= k && !((s <= ez) && e > 0);      // entry 0 always stays (the reference's k > 0)
                 m = (unsigned)(__ballot(stay) >> gl0) & ((1u << kCoopW) - 1u);
                 const bool lower = rowact && m == 0;       // the whole window is popped: the top moves into the block below
@@ -540,18 +531,15 @@ __global__ __launch_bounds__(64) void k_dt_coop(DpParams p)
                 if (lower) { wbase -= kCoopW; k = wbase + kCoopW - 1; ez = zs[wbase + sub]; ey = ys[wbase + sub]; ev = vs[wbase + sub]; }
             }
             const int top = wbase + (rowact ? 31 - __clz((int)m) : 0);     // the highest entry that stays
-            pz = __shfl(s, gl0 + (top & (kCoopW - 1)));                     // its intersection with q: z of the pushed entry
+            const float snew = __shfl(s, gl0 + (top & (kCoopW - 1)));       // its intersection with q: z of the pushed entry
             if (rowact) {
                 k = top + 1;
                 if ((k & (kCoopW - 1)) == 0) wbase = k;                      // the pushed entry opens a new block
-                pl = k & (kCoopW - 1); pk = k;
-                if (sub == pl) { ev = q; ey = yq; ys[k] = yq; vs[k] = q; }
+                if (sub == (k & (kCoopW - 1))) { ev = q; ey = yq; ez = snew; zs[k] = snew; ys[k] = yq; vs[k] = q; }
             }
-            yq = ynext;
         }
         cur = nxt;
     }
-    if (sub == pl) { ez = pz; zs[pk] = pz; }                                 // the last pushed entry's z
     // ---- read-out: sixteen positions of the row at a time
     for (int p0 = 0; p0 < Nmax; p0 += kCoopW) {
         const int pq = p0 + sub;
