@@ -540,7 +540,7 @@ public:
 
 // A stream of single frames over K handles (K HIP streams + workspaces) of one GPU, fed round-robin -- new surface: the
 // reference's callers run detect(im) one frame at a time (cells/detect.cpp:213, ros/Node.cpp:144), and one frame's kernels do
-// not fill an MI355X; frames on different handles overlap at kernel granularity (one 640x480 frame: 416 -> 511 frames/s with
+// not fill an MI355X; frames on different handles overlap at kernel granularity (one 640x480 frame: 423 -> 525 frames/s with
 // four handles).  Results come back in submission order and are those of detect() on one handle.
 //     FrameStream<float> fs(model, 4);
 //     for (;;) { while (fs.full()) { fs.next(cands); use(cands); }   fs.submit(frame); }

@@ -397,7 +397,7 @@ class DetectorPool:
 
     A handle runs its kernels in order on its own stream; the kernels of a small batch do not fill the chip (a single frame's
     launches are smaller than the chip).  Batches submitted to DIFFERENT handles overlap at kernel granularity.  Measured on
-    MI355X: one 640x480 frame per step 416 -> 511 detections/s with four handles, one 1920x1080 frame 84 -> 101 with three;
+    MI355X: one 640x480 frame per step 423 -> 525 detections/s with four handles, one 1920x1080 frame 83 -> 103 with three;
     batches that fill the chip (64 x 640x480, 8 x 1920x1080) gain nothing (profiles/r03_bench_*s*.json,
     profiles/r03_streams_*.txt).  Results come back in submission order; every batch is computed by exactly one handle, so
     they are those of a single PartsBasedDetector.
