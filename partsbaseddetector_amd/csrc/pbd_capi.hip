@@ -1161,10 +1161,15 @@ void launch_conv_stage(pbd_handle *h, Plan &P, int f0, int nb, hipStream_t st)
         // few workgroups (single frame): split the filter groups over more workgroups to fill the chip
         const long long wgs = (long long)P.ntiles * nb;
         cp.groups_per_block = wgs >= 1024 ? ngroups : std::max(1, (int)(ngroups * wgs / 1024));
-        {   // channels staged at a time: all 32 when the haloed tile fits the CU's LDS, else the largest power of two within 64 KB
+        {   // Channels of the haloed tile staged in LDS at a time (generic kernel).  All 32 staged once is the least work, but 110 KB
+            // (T = double, 5 x 5) leaves ONE workgroup -- one wave per SIMD -- on a CU and the kernel then waits for its own LDS
+            // reads: the largest block within 36 KB (four or more workgroups per CU) is taken, restaged per filter group.
+            // Measured, one 640x480 frame, T = double: 9.84 ms with 32 channels -> see profiles/README.md.
+            static const int env_cb = getenv("PBD_CONV_CBLOCK") ? atoi(getenv("PBD_CONV_CBLOCK")) : 0;
             const size_t plane = (size_t)(((kConvTH + C.K - 1) * (kConvTW + C.K - 1)) | 1) * h->rs;
             cp.cblock = 32;
-            if (32 * plane > (size_t)160 * 1024) { cp.cblock = 16; while (cp.cblock > 1 && cp.cblock * plane > (size_t)64 * 1024) cp.cblock /= 2; }
+            while (cp.cblock > 1 && cp.cblock * plane > (size_t)36 * 1024) cp.cblock /= 2;
+            if (env_cb > 0 && env_cb <= 32 && (size_t)env_cb * plane <= (size_t)160 * 1024) cp.cblock = env_cb;
         }
         cp.wts3 = C.wts3.p;
         cp.unit_f0 = C.unit_f0.d; cp.unit_ql = C.unit_ql.d; cp.unit_woff = C.unit_woff.d; cp.nunits = C.nunits;

@@ -373,13 +373,15 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void k_conv3(ConvParams 
 
 // generic kernel: any filter size, any real type R (the reference's T=double instantiation runs here);
 // one output pixel per thread, weights [channel][tap][Fpad] read with wave-uniform vector loads
-template <typename R, bool FMA>
+// KT: the filter side at compile time (5: the tap loops unroll, so the 25 wave-uniform weight loads and LDS reads of a channel are
+// issued in batches instead of one wait per tap) or 0 for any size
+template <typename R, bool FMA, int KT>
 __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     R *smd = reinterpret_cast<R *>(smraw);
     constexpr int TW = kConvTW, TH = kConvTH, Q = kConvQ;
-    const int K = p.ksize;
+    const int K = KT ? KT : p.ksize;
     const int PW = TW + K - 1, PH = TH + K - 1;
     const int PLANE = (PH * PW) | 1;
     const ConvTile tile = p.tiles[blockIdx.x];
@@ -424,16 +426,26 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvParams p)
             R s[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) s[q] = (R)0;
-            for (int i = 0; i < K; ++i) {
-                for (int j = 0; j < K; ++j) {
-                    const R f = sp[i * PW + j];
-                    const R *w = wp + (size_t)(i * K + j) * p.Fpad;
+            // the weights of a tap are wave-uniform and read-only: through the constant address space they come in on the scalar
+            // unit (s_load into SGPRs, used as the scalar operand of the multiply) instead of as 64-lane vector loads of one address
+            typedef const R __attribute__((address_space(4))) cR;
+            auto tap = [&](int i, int j) {
+                const R f = sp[i * PW + j];
+                cR *w = (cR *)(wp + (size_t)(i * K + j) * p.Fpad);
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        if (FMA) s[q] = __builtin_fma(w[q], f, s[q]);
-                        else s[q] = s[q] + w[q] * f;
-                    }
+                for (int q = 0; q < Q; ++q) {
+                    if (FMA) s[q] = __builtin_fma(w[q], f, s[q]);
+                    else s[q] = s[q] + w[q] * f;
                 }
+            };
+            if (KT) {
+#pragma unroll
+                for (int i = 0; i < (KT ? KT : 1); ++i)
+#pragma unroll
+                    for (int j = 0; j < (KT ? KT : 1); ++j) tap(i, j);
+            } else {
+                for (int i = 0; i < K; ++i)
+                    for (int j = 0; j < K; ++j) tap(i, j);
             }
 #pragma unroll
             for (int q = 0; q < Q; ++q) r[q] = r[q] + s[q];
@@ -460,8 +472,13 @@ static void launch_generic(const ConvParams &p, dim3 grid, hipStream_t s)
 {
     const int PW = kConvTW + p.ksize - 1, PH = kConvTH + p.ksize - 1;
     const size_t lds = (size_t)p.cblock * ((PH * PW) | 1) * sizeof(R);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_generic<R, FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    PBD_LAUNCH((k_conv_generic<R, FMA>), grid, dim3(256), lds, s, p);
+    if (p.ksize == 5) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_generic<R, FMA, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PBD_LAUNCH((k_conv_generic<R, FMA, 5>), grid, dim3(256), lds, s, p);
+        return;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_generic<R, FMA, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    PBD_LAUNCH((k_conv_generic<R, FMA, 0>), grid, dim3(256), lds, s, p);
 }
 
 template <bool FMA, int NW>
