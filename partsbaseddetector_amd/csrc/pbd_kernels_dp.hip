@@ -369,7 +369,8 @@ void launch_dt_rows(const DpParams &p0, int nframes, bool f64, hipStream_t s)
     dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_ROWS(PT, BZ)                                                                                              \
     do {                                                                                                              \
-        if (f64) PBD_LAUNCH((k_dt_rows<double, false, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);          \
+        if (f64 && p.lane_shift > 0) PBD_LAUNCH((k_dt_rows<double, false, PT, BZ, true>), grid, dim3(64 * kDtWaves), 0, s, p); \
+        else if (f64) PBD_LAUNCH((k_dt_rows<double, false, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);          \
         else if (p.resp_half) PBD_LAUNCH((k_dt_rows<float, true, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p); \
         else if (p.lane_shift > 0) PBD_LAUNCH((k_dt_rows<float, false, PT, BZ, true>), grid, dim3(64 * kDtWaves), 0, s, p); \
         else PBD_LAUNCH((k_dt_rows<float, false, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);               \
@@ -444,7 +445,8 @@ void launch_dt_cols(const DpParams &p0, int nframes, bool f64, hipStream_t s)
     dim3 grid(p.JG, nframes, nwv << p.lane_shift);
 #define PBD_COLS(PT, BZ)                                                                                   \
     do {                                                                                                   \
-        if (f64) PBD_LAUNCH((k_dt_cols<double, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);      \
+        if (f64 && p.lane_shift > 0) PBD_LAUNCH((k_dt_cols<double, PT, BZ, true>), grid, dim3(64 * kDtWaves), 0, s, p); \
+        else if (f64) PBD_LAUNCH((k_dt_cols<double, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);      \
         else if (p.lane_shift > 0) PBD_LAUNCH((k_dt_cols<float, PT, BZ, true>), grid, dim3(64 * kDtWaves), 0, s, p); \
         else PBD_LAUNCH((k_dt_cols<float, PT, BZ, false>), grid, dim3(64 * kDtWaves), 0, s, p);           \
     } while (0)
