@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void k_dt_rows(DpParams p)
     // the large levels are dispatched first and the tail of the launch is made of short ones
     // lane_shift (0 .. 6): a group of 64 flat rows is spread over 1 .. 64 waves that use their first 64 .. 1 lanes only.
     // A launch that does not fill the chip anyway (one frame, a few 1080p frames) then runs as more, narrower waves: the wave's
-    // pop loops iterate for the slowest of 16 lanes instead of 64, and the launch takes what its longest rows take (launch_dt_rows).
+    // pop loops iterate for the slowest of a few lanes instead of 64, and the launch takes what its longest rows take (launch_dt_rows).
     static_assert(kDtWaves == 1, "one wave per workgroup");
     const int sh = p.lane_shift, lanep = threadIdx.x;
     if (lanep >= (64 >> sh)) return;
@@ -463,7 +463,7 @@ void launch_dt_cols(const DpParams &p0, int nframes, bool f64, hipStream_t s)
 // Inserting element q evaluates the reference's pop predicate -- s(v[e], q) <= z[e] && e > 0, the same expression on the same
 // operands -- for all window entries AT ONCE; the sequential loop pops from the top until the first entry whose predicate is
 // false, i.e. the new top is the highest entry that stays (ballot + find-first-bit) and the pushed z is that entry's
-// intersection.  No pop loop, no divergence: ~60 instructions per element for four rows, whatever the data.  The read-out is
+// intersection.  No pop loop, no divergence: about 95 instructions per element for four rows, whatever the data.  The read-out is
 // a binary search of the (increasing) z of the finished envelope in LDS for sixteen positions of a row at a time:
 // max{k : z[k] < os + q}, what the reference's "while (z[k+1] < os) k++" selects.  Outputs as in the plain passes.
 // G rows per wave, W = 64 / G lanes each (G = 4: window of 16 entries; G = 8: window of 8 -- half the waves for launches that
